@@ -1,0 +1,136 @@
+/*
+ * orb_oracle.h -- CPU restatement ("oracle") of the reference ORB front-end.
+ *
+ * TEST INFRASTRUCTURE ONLY.  Nothing under my-slam_amd/ may include, link or call this.
+ * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg use it, as the checker
+ * and as the reported CPU baseline ("kind": "port").
+ *
+ * PARITY UNPINNED: the reference (WChen09/My-SLAM) ships no tests, fixtures or golden vectors for
+ * this path and cannot be built here (needs OpenCV 3.1.0, absent; writing stand-in
+ * headers for it is not allowed).  Four of the stages' arithmetic lives in OpenCV 3.1.0 (resize,
+ * FAST, GaussianBlur, fastAtan2/cvRound), restated here from its published algorithm; every such
+ * decision point is marked "OpenCV 3.1.0:" in orb_oracle.c.  The reference's own logic is restated
+ * line by line with file:line citations (paths relative to /root/reference).
+ */
+#ifndef ORB_ORACLE_H
+#define ORB_ORACLE_H
+
+#include <stdint.h>
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ORO_MAX_LEVELS 16
+#define ORO_EDGE_THRESHOLD 19   /* src/ORBextractor.cc:76 */
+#define ORO_HALF_PATCH 15       /* src/ORBextractor.cc:75 */
+#define ORO_PATCH_SIZE 31       /* src/ORBextractor.cc:74 */
+
+/* cv::KeyPoint field layout (28 bytes): Point2f pt; float size, angle, response; int octave, class_id */
+typedef struct {
+    float x, y;
+    float size;
+    float angle;
+    float response;
+    int32_t octave;
+    int32_t class_id;
+} oro_keypoint;
+
+/* FAST candidate before distribution: integer coordinates relative to (minBorderX,minBorderY) */
+typedef struct {
+    int32_t x, y;
+    int32_t response;
+} oro_cand;
+
+enum { ORO_BLUR_SCALAR = 0,   /* OpenCV portable C column pass: (sum + 32768) >> 16           */
+       ORO_BLUR_X86_SIMD = 1  /* OpenCV SSE2 column pass for x < (w & ~3): round-half-to-even  */ };
+
+typedef struct {
+    int nfeatures;
+    float scale_factor;
+    int nlevels;
+    int ini_th_fast, min_th_fast;
+    float scale[ORO_MAX_LEVELS];        /* mvScaleFactor      */
+    float inv_scale[ORO_MAX_LEVELS];    /* mvInvScaleFactor   */
+    float sigma2[ORO_MAX_LEVELS];       /* mvLevelSigma2      */
+    float inv_sigma2[ORO_MAX_LEVELS];   /* mvInvLevelSigma2   */
+    int quota[ORO_MAX_LEVELS];          /* mnFeaturesPerLevel */
+    int umax[ORO_HALF_PATCH + 1];
+    int gauss_k[7];                     /* 7x7 sigma=2 kernel x256, per pass */
+    int blur_mode;
+} oro_extractor;
+
+/* ---- A1: constructor tables (src/ORBextractor.cc:412-472) ---- */
+int oro_extractor_init(oro_extractor *e, int nfeatures, float scale_factor, int nlevels,
+                       int ini_th, int min_th);
+void oro_level_size(const oro_extractor *e, int W, int H, int level, int *w, int *h);
+const signed char *oro_pattern(void);           /* 1024 int8 */
+
+/* ---- OpenCV primitive restatements ---- */
+int oro_cv_round(double v);                     /* cvRound: round half to even */
+float oro_fast_atan2(float y, float x);         /* cv::fastAtan2, degrees */
+void oro_sincos_deg(float angle_deg, float *a_cos, float *b_sin); /* :114-115, correctly rounded */
+int oro_reflect101(int p, int len);
+void oro_resize_linear(const uint8_t *src, int sw, int sh, int sstride,
+                       uint8_t *dst, int dw, int dh, int dstride);
+void oro_copy_make_border101(const uint8_t *src, int w, int h, int sstride,
+                             uint8_t *dst, int dstride, int border);
+void oro_gaussian_blur7(const uint8_t *src, int w, int h, int sstride,
+                        uint8_t *dst, int dstride, const int k[7], int mode);
+/* cv::FAST(img, kps, threshold, nonmax, TYPE_9_16) on a cols x rows view; returns count (<= cap). */
+int oro_fast9_16(const uint8_t *img, int stride, int cols, int rows, int threshold, int nonmax,
+                 oro_cand *out, int cap);
+/* threshold-free corner score of one pixel: max over 9-arcs of min |diff|, minus 1 (may be < 0) */
+int oro_fast_score_pixel(const uint8_t *p, int stride);
+
+/* ---- A2..A8 ---- */
+/* levels[l] must hold w_l*h_l bytes, contiguous (stride = w_l), interior only */
+void oro_compute_pyramid(const oro_extractor *e, const uint8_t *img, int W, int H, int stride,
+                         uint8_t *const *levels);
+/* A3 cell loop for one level; returns the number of candidates (<= cap), -1 on overflow */
+int oro_detect_level(const oro_extractor *e, const uint8_t *lvl, int w, int h, int stride,
+                     oro_cand *out, int cap);
+/* A4; returns the number kept, written as indices into cands (order = list order) */
+int oro_distribute_octree(const oro_cand *cands, int n, int minX, int maxX, int minY, int maxY,
+                          int N, int32_t *out_idx, int cap);
+float oro_ic_angle(const uint8_t *lvl, int stride, int x, int y, const int umax[16]);
+void oro_descriptor(const uint8_t *blurred, int stride, int x, int y, float angle_deg,
+                    uint8_t desc[32]);
+/*
+ * A8 operator().  kps/desc capacity cap; *n receives the count.  level_out (optional, may be NULL)
+ * receives nlevels pointers that the caller has sized via oro_level_size.  n_per_level optional.
+ * Returns 0, or <0: -1 bad args, -2 capacity, -3 unsupported shape (reference UB).
+ */
+int oro_extract(const oro_extractor *e, const uint8_t *img, int W, int H, int stride,
+                oro_keypoint *kps, uint8_t *desc, int cap, int *n,
+                uint8_t *const *level_out, int *n_per_level);
+
+/* ---- A9..A11 matcher ---- */
+int oro_descriptor_distance(const uint8_t a[32], const uint8_t b[32]);  /* src/ORBmatcher.cc:1647 */
+/*
+ * best / second-best over candidate lists (SearchByBoW inner loop, src/ORBmatcher.cc:201-226).
+ * cand_off NULL => dense (every query against train 0..nt-1 in order).
+ */
+void oro_best2(const uint8_t *q, int nq, const uint8_t *t, int nt,
+               const int32_t *cand_off, const int32_t *cand_idx,
+               int32_t *best_idx, int32_t *best_d, int32_t *second_d);
+void oro_three_maxima(const int *hist_sizes, int L, int *ind1, int *ind2, int *ind3); /* :1601 */
+int oro_rot_bin(float angle1, float angle2);  /* :236-244 */
+/*
+ * Rotation-consistency filter (:236-246 fill + :266-284 cull): match12[i] = train index or -1;
+ * culled entries are set to -1.  Returns surviving match count.
+ */
+int oro_rot_filter(const float *angle_q, const float *angle_t, int32_t *match12, int nq);
+/*
+ * Dense frame-vs-frame matching with the SearchByBoW acceptance (<= th, ratio) on stateless best2,
+ * then the rotation filter.  Used for BASELINE config 3.  Returns match count.
+ */
+int oro_match_dense(const uint8_t *q, const float *angle_q, int nq,
+                    const uint8_t *t, const float *angle_t, int nt,
+                    int th, float nnratio, int check_ori, int32_t *match12);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,188 @@
+"""ctypes binding to oracle/liborb_oracle.so (the CPU restatement).  Test infrastructure only."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ORACLE_DIR = os.path.join(ROOT, "oracle")
+MAX_LEVELS = 16
+
+KP_DTYPE = np.dtype([("x", "<f4"), ("y", "<f4"), ("size", "<f4"), ("angle", "<f4"),
+                     ("response", "<f4"), ("octave", "<i4"), ("class_id", "<i4")])
+CAND_DTYPE = np.dtype([("x", "<i4"), ("y", "<i4"), ("response", "<i4")])
+assert KP_DTYPE.itemsize == 28 and CAND_DTYPE.itemsize == 12
+
+
+class OroExtractor(C.Structure):
+    _fields_ = [("nfeatures", C.c_int), ("scale_factor", C.c_float), ("nlevels", C.c_int),
+                ("ini_th_fast", C.c_int), ("min_th_fast", C.c_int),
+                ("scale", C.c_float * MAX_LEVELS), ("inv_scale", C.c_float * MAX_LEVELS),
+                ("sigma2", C.c_float * MAX_LEVELS), ("inv_sigma2", C.c_float * MAX_LEVELS),
+                ("quota", C.c_int * MAX_LEVELS), ("umax", C.c_int * 16), ("gauss_k", C.c_int * 7),
+                ("blur_mode", C.c_int)]
+
+
+_lib = None
+
+
+def build(native=False):
+    target = "liborb_oracle_native.so" if native else "liborb_oracle.so"
+    subprocess.check_call(["make", "-s", "-C", ORACLE_DIR, target])
+    return os.path.join(ORACLE_DIR, target)
+
+
+def lib(native=False):
+    global _lib
+    if _lib is not None and not native:
+        return _lib
+    path = build(native)
+    L = C.CDLL(path)
+    u8p, i32p, f32p = C.POINTER(C.c_uint8), C.POINTER(C.c_int32), C.POINTER(C.c_float)
+    vp = C.c_void_p
+    L.oro_extractor_init.argtypes = [C.POINTER(OroExtractor), C.c_int, C.c_float, C.c_int, C.c_int, C.c_int]
+    L.oro_extractor_init.restype = C.c_int
+    L.oro_level_size.argtypes = [C.POINTER(OroExtractor), C.c_int, C.c_int, C.c_int,
+                                 C.POINTER(C.c_int), C.POINTER(C.c_int)]
+    L.oro_pattern.restype = C.POINTER(C.c_int8)
+    L.oro_cv_round.argtypes = [C.c_double]
+    L.oro_cv_round.restype = C.c_int
+    L.oro_fast_atan2.argtypes = [C.c_float, C.c_float]
+    L.oro_fast_atan2.restype = C.c_float
+    L.oro_sincos_deg.argtypes = [C.c_float, f32p, f32p]
+    L.oro_reflect101.argtypes = [C.c_int, C.c_int]
+    L.oro_reflect101.restype = C.c_int
+    L.oro_resize_linear.argtypes = [vp, C.c_int, C.c_int, C.c_int, vp, C.c_int, C.c_int, C.c_int]
+    L.oro_copy_make_border101.argtypes = [vp, C.c_int, C.c_int, C.c_int, vp, C.c_int, C.c_int]
+    L.oro_gaussian_blur7.argtypes = [vp, C.c_int, C.c_int, C.c_int, vp, C.c_int, C.POINTER(C.c_int), C.c_int]
+    L.oro_fast9_16.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp, C.c_int]
+    L.oro_fast9_16.restype = C.c_int
+    L.oro_fast_score_pixel.argtypes = [vp, C.c_int]
+    L.oro_fast_score_pixel.restype = C.c_int
+    L.oro_detect_level.argtypes = [C.POINTER(OroExtractor), vp, C.c_int, C.c_int, C.c_int, vp, C.c_int]
+    L.oro_detect_level.restype = C.c_int
+    L.oro_distribute_octree.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp, C.c_int]
+    L.oro_distribute_octree.restype = C.c_int
+    L.oro_ic_angle.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int)]
+    L.oro_ic_angle.restype = C.c_float
+    L.oro_descriptor.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_float, vp]
+    L.oro_extract.argtypes = [C.POINTER(OroExtractor), vp, C.c_int, C.c_int, C.c_int, vp, vp, C.c_int,
+                              C.POINTER(C.c_int), C.POINTER(C.c_void_p), C.POINTER(C.c_int)]
+    L.oro_extract.restype = C.c_int
+    L.oro_descriptor_distance.argtypes = [vp, vp]
+    L.oro_descriptor_distance.restype = C.c_int
+    L.oro_best2.argtypes = [vp, C.c_int, vp, C.c_int, vp, vp, vp, vp, vp]
+    L.oro_three_maxima.argtypes = [C.POINTER(C.c_int), C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]
+    L.oro_rot_bin.argtypes = [C.c_float, C.c_float]
+    L.oro_rot_bin.restype = C.c_int
+    L.oro_rot_filter.argtypes = [vp, vp, vp, C.c_int]
+    L.oro_rot_filter.restype = C.c_int
+    L.oro_match_dense.argtypes = [vp, vp, C.c_int, vp, vp, C.c_int, C.c_int, C.c_float, C.c_int, vp]
+    L.oro_match_dense.restype = C.c_int
+    if not native:
+        _lib = L
+    return L
+
+
+def _p(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+class Extractor:
+    """Mirror of ORBextractor(nfeatures, scaleFactor, nlevels, iniThFAST, minThFAST) on the oracle."""
+
+    def __init__(self, nfeatures=1000, scale_factor=1.2, nlevels=8, ini_th=20, min_th=7,
+                 blur_mode=0, native=False):
+        self.L = lib(native)
+        self.e = OroExtractor()
+        rc = self.L.oro_extractor_init(C.byref(self.e), nfeatures, scale_factor, nlevels, ini_th, min_th)
+        if rc != 0:
+            raise ValueError("oro_extractor_init rc=%d" % rc)
+        self.e.blur_mode = blur_mode
+        self.nlevels = nlevels
+        self.nfeatures = nfeatures
+
+    def level_size(self, W, H, level):
+        w, h = C.c_int(), C.c_int()
+        self.L.oro_level_size(C.byref(self.e), W, H, level, C.byref(w), C.byref(h))
+        return w.value, h.value
+
+    def level_sizes(self, W, H):
+        return [self.level_size(W, H, l) for l in range(self.nlevels)]
+
+    def pyramid(self, img):
+        img = np.ascontiguousarray(img, dtype=np.uint8)
+        H, W = img.shape
+        out = [np.empty((h, w), dtype=np.uint8) for (w, h) in self.level_sizes(W, H)]
+        src = img
+        out[0][:] = img
+        for l in range(1, self.nlevels):
+            h, w = out[l].shape
+            self.L.oro_resize_linear(_p(out[l - 1]), out[l - 1].shape[1], out[l - 1].shape[0],
+                                     out[l - 1].shape[1], _p(out[l]), w, h, w)
+        return out
+
+    def detect_level(self, lvl, cap=1 << 20):
+        lvl = np.ascontiguousarray(lvl, dtype=np.uint8)
+        h, w = lvl.shape
+        out = np.empty(cap, dtype=CAND_DTYPE)
+        n = self.L.oro_detect_level(C.byref(self.e), _p(lvl), w, h, w, _p(out), cap)
+        if n < 0:
+            raise RuntimeError("oro_detect_level overflow")
+        return out[:n].copy()
+
+    def extract(self, img, cap=None, want_levels=False):
+        img = np.ascontiguousarray(img, dtype=np.uint8)
+        H, W = img.shape
+        if cap is None:
+            cap = self.nfeatures + 4 * self.nlevels + 4096
+        kps = np.zeros(cap, dtype=KP_DTYPE)
+        desc = np.zeros((cap, 32), dtype=np.uint8)
+        n = C.c_int()
+        npl = (C.c_int * MAX_LEVELS)()
+        levels = None
+        lv_ptrs = None
+        if want_levels:
+            levels = [np.empty((h, w), dtype=np.uint8) for (w, h) in self.level_sizes(W, H)]
+            lv_ptrs = (C.c_void_p * self.nlevels)(*[a.ctypes.data for a in levels])
+        rc = self.L.oro_extract(C.byref(self.e), _p(img), W, H, img.strides[0], _p(kps), _p(desc), cap,
+                                C.byref(n), lv_ptrs, npl)
+        if rc != 0:
+            raise RuntimeError("oro_extract rc=%d" % rc)
+        res = (kps[:n.value].copy(), desc[:n.value].copy(), list(npl)[:self.nlevels])
+        return res + (levels,) if want_levels else res
+
+
+def distribute_octree(cands, minX, maxX, minY, maxY, N):
+    L = lib()
+    cands = np.ascontiguousarray(cands, dtype=CAND_DTYPE)
+    out = np.empty(max(len(cands), 1), dtype=np.int32)
+    n = L.oro_distribute_octree(_p(cands), len(cands), minX, maxX, minY, maxY, N, _p(out), len(out))
+    if n < 0:
+        raise RuntimeError("oro_distribute_octree rc=%d" % n)
+    return out[:n].copy()
+
+
+def best2(q, t, cand_off=None, cand_idx=None):
+    L = lib()
+    q = np.ascontiguousarray(q, dtype=np.uint8)
+    t = np.ascontiguousarray(t, dtype=np.uint8)
+    nq, nt = len(q), len(t)
+    bi = np.empty(nq, np.int32); bd = np.empty(nq, np.int32); sd = np.empty(nq, np.int32)
+    if cand_off is not None:
+        cand_off = np.ascontiguousarray(cand_off, dtype=np.int32)
+        cand_idx = np.ascontiguousarray(cand_idx, dtype=np.int32)
+        L.oro_best2(_p(q), nq, _p(t), nt, _p(cand_off), _p(cand_idx), _p(bi), _p(bd), _p(sd))
+    else:
+        L.oro_best2(_p(q), nq, _p(t), nt, None, None, _p(bi), _p(bd), _p(sd))
+    return bi, bd, sd
+
+
+def match_dense(q, aq, t, at, th=50, nnratio=0.9, check_ori=True):
+    L = lib()
+    q = np.ascontiguousarray(q, dtype=np.uint8); t = np.ascontiguousarray(t, dtype=np.uint8)
+    aq = np.ascontiguousarray(aq, dtype=np.float32); at = np.ascontiguousarray(at, dtype=np.float32)
+    m = np.empty(len(q), np.int32)
+    n = L.oro_match_dense(_p(q), _p(aq), len(q), _p(t), _p(at), len(t), th, nnratio, int(check_ori), _p(m))
+    return n, m
