@@ -1,0 +1,232 @@
+"""my-slam_amd: MI355X-native ORB front-end (extractor + Hamming matcher) behind a C ABI.
+
+The product is `lib/liborbx.so` (hand-written HIP for gfx950, see csrc/).  This module is only the
+ctypes plumbing the tests and bench.py use to reach that C ABI from Python; there is no CPU path:
+if the library is missing or no HIP device is present every entry point raises.
+
+The directory name carries a hyphen (the framework's name); load it with
+    importlib.util.spec_from_file_location("my_slam_amd", "<repo>/my-slam_amd/__init__.py")
+or via tests/conftest.py / the loader at the top of bench.py.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+PKG_DIR = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(PKG_DIR, "lib", "liborbx.so")
+
+KP_DTYPE = np.dtype([("x", "<f4"), ("y", "<f4"), ("size", "<f4"), ("angle", "<f4"),
+                     ("response", "<f4"), ("octave", "<i4"), ("class_id", "<i4")])
+assert KP_DTYPE.itemsize == 28
+
+ORBX_OK = 0
+ORBX_E_INVALID, ORBX_E_CAPACITY, ORBX_E_SHAPE, ORBX_E_HIP, ORBX_E_CAND_OVERFLOW, ORBX_E_TREE_OVERFLOW = -1, -2, -3, -4, -5, -6
+ORBX_OPT_BLUR_ROUNDING = 1
+
+
+class OrbxError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__("orbx status %d: %s" % (code, msg))
+        self.code = code
+
+
+def build(verbose=False):
+    """Compile lib/liborbx.so for gfx950 with hipcc (cross-compiles without a GPU)."""
+    subprocess.check_call(["make", "-C", PKG_DIR] + ([] if verbose else ["-s"]))
+    return LIB_PATH
+
+
+_lib = None
+
+
+def lib():
+    """The loaded C-ABI library.  Raises if it has not been built: there is no fallback."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise OrbxError(ORBX_E_HIP, "%s is missing: run __graft_entry__.build() / make -C my-slam_amd" % LIB_PATH)
+    L = C.CDLL(LIB_PATH)
+    vp, ip = C.c_void_p, C.POINTER(C.c_int)
+    L.orbx_create.argtypes = [C.POINTER(vp), C.c_int, C.c_float, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]
+    L.orbx_create.restype = C.c_int
+    L.orbx_destroy.argtypes = [vp]
+    L.orbx_destroy.restype = None
+    L.orbx_set_option.argtypes = [vp, C.c_int, C.c_int]
+    L.orbx_get_levels.argtypes = [vp]
+    L.orbx_get_scale_factor.argtypes = [vp]
+    L.orbx_get_scale_factor.restype = C.c_float
+    L.orbx_get_tables.argtypes = [vp, vp, vp, vp, vp]
+    L.orbx_get_features_per_level.argtypes = [vp, vp]
+    L.orbx_capacity.argtypes = [vp]
+    L.orbx_extract.argtypes = [vp, vp, C.c_int, C.c_int, C.c_int, vp, vp, C.c_int, ip]
+    L.orbx_extract_batch.argtypes = [vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_size_t, vp, vp, C.c_int, vp]
+    L.orbx_extract_batch_device.argtypes = [vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_size_t, vp, vp, C.c_int, vp, vp, vp]
+    L.orbx_level_size.argtypes = [vp, C.c_int, ip, ip]
+    L.orbx_download_level.argtypes = [vp, C.c_int, C.c_int, vp, C.c_int, C.c_int]
+    L.orbx_download_candidates.argtypes = [vp, C.c_int, C.c_int, vp, C.c_int]
+    L.orbx_last_stage_ms.argtypes = [vp, vp]
+    L.orbx_set_profiling.argtypes = [vp, C.c_int]
+    L.orbx_last_error.restype = C.c_char_p
+    L.orbx_version.restype = C.c_char_p
+    L.orbx_debug_sincos.argtypes = [vp, vp, vp, C.c_int]
+    for name in ("orbx_set_option", "orbx_get_levels", "orbx_get_tables", "orbx_get_features_per_level",
+                 "orbx_capacity", "orbx_extract", "orbx_extract_batch", "orbx_extract_batch_device",
+                 "orbx_level_size", "orbx_download_level", "orbx_download_candidates", "orbx_last_stage_ms",
+                 "orbx_set_profiling", "orbx_debug_sincos"):
+        getattr(L, name).restype = C.c_int
+    _bind_matcher(L)
+    _lib = L
+    return L
+
+
+def _bind_matcher(L):
+    vp = C.c_void_p
+    if not hasattr(L, "orbm_create"):
+        return
+    L.orbm_create.argtypes = [C.POINTER(vp), C.c_int, C.c_int, C.c_int, C.c_int]
+    L.orbm_destroy.argtypes = [vp]
+    L.orbm_destroy.restype = None
+    L.orbm_distance.argtypes = [vp, vp]
+    L.orbm_best2.argtypes = [vp, vp, C.c_int, vp, C.c_int, vp, vp, vp, vp, vp]
+    L.orbm_distances.argtypes = [vp, vp, C.c_int, vp, C.c_int, vp, vp, vp]
+    L.orbm_best2_batch_device.argtypes = [vp, vp, vp, vp, vp, C.c_int, C.c_int, vp, vp, vp, vp]
+    L.orbm_match_batch_device.argtypes = [vp, vp, vp, vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_float, C.c_int, vp, vp, vp]
+    L.orbm_rot_filter.argtypes = [vp, vp, vp, C.c_int]
+    L.orbm_three_maxima.argtypes = [vp, C.c_int, vp]
+    L.orbm_last_error.restype = C.c_char_p
+    for name in ("orbm_create", "orbm_distance", "orbm_best2", "orbm_distances", "orbm_best2_batch_device",
+                 "orbm_match_batch_device", "orbm_rot_filter", "orbm_three_maxima"):
+        getattr(L, name).restype = C.c_int
+
+
+def _p(a):
+    return a.ctypes.data_as(C.c_void_p) if a is not None else None
+
+
+def _chk(rc):
+    if rc != ORBX_OK:
+        raise OrbxError(rc, lib().orbx_last_error().decode())
+
+
+class ORBextractor:
+    """Python mirror of ORB_SLAM2::ORBextractor (include/ORBextractor.h:46-112) over the C ABI."""
+
+    def __init__(self, nfeatures=1000, scaleFactor=1.2, nlevels=8, iniThFAST=20, minThFAST=7,
+                 device=0, max_width=640, max_height=480, max_batch=1):
+        self.L = lib()
+        self.h = C.c_void_p()
+        _chk(self.L.orbx_create(C.byref(self.h), nfeatures, scaleFactor, nlevels, iniThFAST, minThFAST,
+                                device, max_width, max_height, max_batch))
+        self.nlevels = nlevels
+        self.max_batch = max_batch
+        self.cap = self.L.orbx_capacity(self.h)
+
+    def close(self):
+        if getattr(self, "h", None) is not None and self.h:
+            self.L.orbx_destroy(self.h)
+            self.h = None
+
+    __del__ = close
+
+    # getters (include/ORBextractor.h:63-83)
+    def GetLevels(self):
+        return self.L.orbx_get_levels(self.h)
+
+    def GetScaleFactor(self):
+        return self.L.orbx_get_scale_factor(self.h)
+
+    def _tables(self):
+        t = [np.zeros(self.nlevels, np.float32) for _ in range(4)]
+        _chk(self.L.orbx_get_tables(self.h, *[_p(a) for a in t]))
+        return t
+
+    def GetScaleFactors(self):
+        return self._tables()[0]
+
+    def GetInverseScaleFactors(self):
+        return self._tables()[1]
+
+    def GetScaleSigmaSquares(self):
+        return self._tables()[2]
+
+    def GetInverseScaleSigmaSquares(self):
+        return self._tables()[3]
+
+    def features_per_level(self):
+        q = np.zeros(self.nlevels, np.int32)
+        _chk(self.L.orbx_get_features_per_level(self.h, _p(q)))
+        return q
+
+    def set_blur_rounding(self, mode):
+        _chk(self.L.orbx_set_option(self.h, ORBX_OPT_BLUR_ROUNDING, mode))
+
+    def set_profiling(self, on):
+        _chk(self.L.orbx_set_profiling(self.h, int(on)))
+
+    def stage_ms(self):
+        ms = np.zeros(4, np.float32)
+        _chk(self.L.orbx_last_stage_ms(self.h, _p(ms)))
+        return ms
+
+    def __call__(self, image, mask=None):
+        """operator()(image, mask, keypoints, descriptors) -> (keypoints[KP_DTYPE], descriptors[n,32])."""
+        if image is None or image.size == 0:
+            return np.zeros(0, KP_DTYPE), np.zeros((0, 32), np.uint8)
+        assert image.dtype == np.uint8 and image.ndim == 2   # assert(image.type() == CV_8UC1), :1052
+        if image.strides[1] != 1:
+            image = np.ascontiguousarray(image)
+        H, W = image.shape
+        kps = np.zeros(self.cap, KP_DTYPE)
+        desc = np.zeros((self.cap, 32), np.uint8)
+        n = C.c_int()
+        _chk(self.L.orbx_extract(self.h, _p(image), W, H, image.strides[0], _p(kps), _p(desc), self.cap, C.byref(n)))
+        return kps[:n.value].copy(), desc[:n.value].copy()
+
+    def extract_batch(self, images):
+        images = np.ascontiguousarray(images, dtype=np.uint8)
+        B, H, W = images.shape
+        kps = np.zeros((B, self.cap), KP_DTYPE)
+        desc = np.zeros((B, self.cap, 32), np.uint8)
+        counts = np.zeros(B, np.int32)
+        _chk(self.L.orbx_extract_batch(self.h, _p(images), B, W, H, images.strides[1], images.strides[0],
+                                       _p(kps), _p(desc), self.cap, _p(counts)))
+        return [(kps[k, :counts[k]].copy(), desc[k, :counts[k]].copy()) for k in range(B)]
+
+    def extract_batch_device(self, d_images_ptr, B, W, H, row_stride, frame_stride,
+                             d_kps_ptr, d_desc_ptr, d_counts_ptr, d_status_ptr, stream=None):
+        """All pointers are device addresses (e.g. torch tensor .data_ptr()); asynchronous."""
+        _chk(self.L.orbx_extract_batch_device(self.h, d_images_ptr, B, W, H, row_stride, frame_stride,
+                                              d_kps_ptr, d_desc_ptr, self.cap, d_counts_ptr, d_status_ptr, stream))
+
+    def level_size(self, level):
+        w, h = C.c_int(), C.c_int()
+        _chk(self.L.orbx_level_size(self.h, level, C.byref(w), C.byref(h)))
+        return w.value, h.value
+
+    def image_pyramid(self, frame=0, border=0):
+        """mvImagePyramid of the last call (host copies)."""
+        out = []
+        for l in range(self.nlevels):
+            w, h = self.level_size(l)
+            a = np.zeros((h + 2 * border, w + 2 * border), np.uint8)
+            _chk(self.L.orbx_download_level(self.h, frame, l, _p(a), a.strides[0], border))
+            out.append(a)
+        return out
+
+    def candidates(self, frame, level, cap=1 << 20):
+        a = np.zeros((cap, 3), np.int32)
+        n = self.L.orbx_download_candidates(self.h, frame, level, _p(a), cap)
+        if n < 0:
+            _chk(n)
+        return a[:n].copy()
+
+
+def debug_sincos(theta):
+    theta = np.ascontiguousarray(theta, np.float32)
+    c = np.empty_like(theta)
+    s = np.empty_like(theta)
+    _chk(lib().orbx_debug_sincos(_p(theta), _p(c), _p(s), len(theta)))
+    return c, s

@@ -1,0 +1,508 @@
+// orbx_capi.hip -- host side of liborbx.so: constructor tables, shape planning, workspace, C ABI.
+// The arithmetic here restates the reference constructor and OpenCV's resize planning on the host
+// (citations: src/ORBextractor.cc of WChen09/My-SLAM); all pixel work is in orbx_kernels.hip.
+#include <cfloat>
+#include <cstdarg>
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "orbx_internal.h"
+
+static thread_local std::string g_err;
+static int fail(int code, const char *fmt, ...)
+{
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    g_err = buf;
+    return code;
+}
+#define HIPCHK(expr)                                                                            \
+    do {                                                                                        \
+        hipError_t e_ = (expr);                                                                 \
+        if (e_ != hipSuccess) return fail(ORBX_E_HIP, "%s: %s", #expr, hipGetErrorString(e_)); \
+    } while (0)
+
+extern "C" const char *orbx_last_error(void) { return g_err.c_str(); }
+extern "C" const char *orbx_version(void) { return "orbx 0.1 (gfx950)"; }
+
+static inline int cv_round(double v) { return (int)lrint(v); }   // cvRound: half to even
+static inline int cv_floor(double v) { int i = (int)v; return i - (v < i); }
+static inline int cv_ceil(double v) { int i = (int)v; return i + (v > i); }
+static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+struct orbx_extractor {
+    int nfeatures = 0; float scale_factor = 0; int nlevels = 0, ini_th = 0, min_th = 0, device = 0;
+    int max_w = 0, max_h = 0, max_batch = 0;
+    float scale[ORBX_MAX_LEVELS], inv_scale[ORBX_MAX_LEVELS], sigma2[ORBX_MAX_LEVELS], inv_sigma2[ORBX_MAX_LEVELS];
+    int quota[ORBX_MAX_LEVELS];
+    int umax[16]; int gauss_k[7];
+    int blur_mode = 0;
+    hipStream_t stream = nullptr;
+    // current plan
+    int cur_w = 0, cur_h = 0; int last_batch = 0;
+    const uint8_t *last_input = nullptr; int last_in_stride = 0; long long last_in_frame = 0;
+    OrbxPlan plan; OrbxWork work; ResizeTab tabs[ORBX_MAX_LEVELS]; int area2[ORBX_MAX_LEVELS];
+    size_t oct_lds = 0;
+    // allocations (sized for the max shape)
+    OrbxPlan max_plan; size_t pyr_bytes = 0; size_t pyr_level_off[ORBX_MAX_LEVELS];
+    uint8_t *d_input = nullptr; int in_stride = 0; size_t in_frame = 0;
+    uint8_t *d_pyr = nullptr;
+    int *d_tab_i = nullptr; short2 *d_tab_s = nullptr; size_t tab_elems = 0;
+    orbx_keypoint *d_kps = nullptr; uint8_t *d_desc = nullptr; int32_t *d_counts = nullptr, *d_status = nullptr;
+    orbx_keypoint *h_kps = nullptr; uint8_t *h_desc = nullptr; int32_t *h_counts = nullptr, *h_status = nullptr;
+    int profiling = 0; hipEvent_t ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr}; float stage_ms[4] = {0, 0, 0, 0};
+};
+
+// ---- A1: ORBextractor::ORBextractor tables (:412-472) ----
+static void build_tables(orbx_extractor *h)
+{
+    const int L = h->nlevels;
+    h->scale[0] = 1.0f; h->sigma2[0] = 1.0f;
+    for (int i = 1; i < L; i++) {
+        h->scale[i] = h->scale[i - 1] * h->scale_factor;
+        h->sigma2[i] = h->scale[i] * h->scale[i];
+    }
+    for (int i = 0; i < L; i++) {
+        h->inv_scale[i] = 1.0f / h->scale[i];
+        h->inv_sigma2[i] = 1.0f / h->sigma2[i];
+    }
+    float factor = 1.0f / h->scale_factor;
+    float nDesired = h->nfeatures * (1 - factor) / (1 - (float)pow((double)factor, (double)L));
+    int sum = 0;
+    for (int level = 0; level < L - 1; level++) {
+        h->quota[level] = cv_round(nDesired);
+        sum += h->quota[level];
+        nDesired *= factor;
+    }
+    h->quota[L - 1] = std::max(h->nfeatures - sum, 0);
+
+    int v, v0, vmax = cv_floor(ORBX_HALF_PATCH * sqrtf(2.f) / 2 + 1);
+    int vmin = cv_ceil(ORBX_HALF_PATCH * sqrtf(2.f) / 2);
+    const double hp2 = ORBX_HALF_PATCH * ORBX_HALF_PATCH;
+    for (v = 0; v <= vmax; ++v) h->umax[v] = cv_round(sqrt(hp2 - v * v));
+    for (v = ORBX_HALF_PATCH, v0 = 0; v >= vmin; --v) {
+        while (h->umax[v0] == h->umax[v0 + 1]) ++v0;
+        h->umax[v] = v0;
+        ++v0;
+    }
+    // OpenCV getGaussianKernel(7, 2, CV_32F) -> x256 fixed point (cv::GaussianBlur u8 path)
+    float cf[7]; double s = 0;
+    for (int i = 0; i < 7; i++) { double x = i - 3.0; cf[i] = (float)exp(-0.5 / 4.0 * x * x); s += cf[i]; }
+    s = 1. / s;
+    for (int i = 0; i < 7; i++) { cf[i] = (float)(cf[i] * s); h->gauss_k[i] = cv_round((double)cf[i] * 256.0); }
+}
+
+// ---- shape planning: level sizes (:1113-1114), cell grid (:775-789), quadtree roots (:545-547) ----
+static int make_plan(const orbx_extractor *h, int W, int H, OrbxPlan *P, std::string *why)
+{
+    memset(P, 0, sizeof(*P));
+    P->nlevels = h->nlevels; P->ini_th = h->ini_th; P->min_th = h->min_th; P->blur_mode = h->blur_mode;
+    long long cand_off = 0, list_off = 0, arena_off = 0;
+    int cells = 0;
+    for (int l = 0; l < h->nlevels; l++) {
+        OrbxLevel &L = P->lv[l];
+        L.w = cv_round((float)W * h->inv_scale[l]);
+        L.h = cv_round((float)H * h->inv_scale[l]);
+        if (L.w < 1 || L.h < 1 || L.w > 65535 || L.h > 65535) { *why = "level size out of range"; return ORBX_E_SHAPE; }
+        L.maxBX = L.w - ORBX_MINB; L.maxBY = L.h - ORBX_MINB;
+        const float width = (float)(L.maxBX - ORBX_MINB), height = (float)(L.maxBY - ORBX_MINB);
+        L.nCols = width > 0 ? (int)(width / 30.f) : 0;
+        L.nRows = height > 0 ? (int)(height / 30.f) : 0;
+        if (L.nCols <= 0 || L.nRows <= 0) { L.nCols = L.nRows = 0; L.wCell = L.hCell = 1; }   // no cell => no keypoint
+        else { L.wCell = (int)ceilf(width / L.nCols); L.hCell = (int)ceilf(height / L.nRows); }
+        L.cell_begin = cells;
+        cells += L.nCols * L.nRows;
+        L.quota = h->quota[l];
+        L.nIni = 0; L.hX = 1.f;
+        if (L.nCols > 0) {
+            L.nIni = (int)roundf(width / (float)(L.maxBY - ORBX_MINB));
+            if (L.nIni <= 0) { *why = "portrait level (quadtree root count 0): undefined in the reference"; return ORBX_E_SHAPE; }
+            L.hX = width / L.nIni;
+        }
+        const long long zone = (long long)std::max(L.w - 2 * ORBX_EDGE, 0) * std::max(L.h - 2 * ORBX_EDGE, 0);
+        L.cand_cap = L.nCols > 0 ? (int)std::min<long long>(zone / 8 + 256, (1 << 20) - 1) : 0;
+        L.cand_off = cand_off; cand_off += (L.cand_cap + 15) / 16 * 16;
+        L.list_cap = L.nCols > 0 ? (std::max(L.quota + 3, 4 * L.nIni) + 1 + 3) / 4 * 4 : 0;
+        L.list_off = list_off; list_off += L.list_cap;
+        L.arena_cap = L.nCols > 0 ? 24 * L.list_cap + 256 : 0;
+        L.arena_off = arena_off; arena_off += L.arena_cap;
+        L.scale = h->scale[l];
+        L.kp_size = (float)(int)(31 * h->scale[l]);   // :839,:848
+    }
+    P->ncells = cells;
+    P->cand_frame = cand_off; P->list_frame = list_off; P->arena_frame = arena_off;
+    P->out_cap = (int)list_off;
+    return ORBX_OK;
+}
+
+// cv::resize INTER_LINEAR planning for one level pair (OpenCV 3.1.0 imgwarp.cpp)
+static void plan_resize(int sw, int sh, int dw, int dh, int *xofs, short2 *alpha, int *yofs, short2 *beta, int *area2)
+{
+    const double inv_x = (double)dw / sw, inv_y = (double)dh / sh;
+    const double scale_x = 1. / inv_x, scale_y = 1. / inv_y;
+    const int isx = cv_round(scale_x), isy = cv_round(scale_y);
+    *area2 = fabs(scale_x - isx) < DBL_EPSILON && fabs(scale_y - isy) < DBL_EPSILON && isx == 2 && isy == 2;
+    auto sat = [](float v) { int i = cv_round(v); return (short)(i < -32768 ? -32768 : i > 32767 ? 32767 : i); };
+    for (int dx = 0; dx < dw; dx++) {
+        float fx = (float)((dx + 0.5) * scale_x - 0.5);
+        int sx = cv_floor(fx);
+        fx -= sx;
+        if (sx < 0) { fx = 0; sx = 0; }
+        if (sx >= sw - 1) { fx = 0; sx = sw - 1; }
+        xofs[dx] = sx;
+        alpha[dx] = make_short2(sat((1.f - fx) * 2048), sat(fx * 2048));
+    }
+    for (int dy = 0; dy < dh; dy++) {
+        float fy = (float)((dy + 0.5) * scale_y - 0.5);
+        int sy = cv_floor(fy);
+        fy -= sy;
+        yofs[dy] = sy;
+        beta[dy] = make_short2(sat((1.f - fy) * 2048), sat(fy * 2048));
+    }
+}
+
+static void free_all(orbx_extractor *h)
+{
+    if (!h) return;
+    hipSetDevice(h->device);
+    hipFree(h->d_input); hipFree(h->d_pyr); hipFree(h->d_tab_i); hipFree(h->d_tab_s);
+    hipFree(h->work.cand); hipFree(h->work.cand_count); hipFree(h->work.owner); hipFree(h->work.arena);
+    hipFree(h->work.sel); hipFree(h->work.nk); hipFree(h->work.errflags);
+    hipFree(h->d_kps); hipFree(h->d_desc); hipFree(h->d_counts); hipFree(h->d_status);
+    hipHostFree(h->h_kps); hipHostFree(h->h_desc); hipHostFree(h->h_counts); hipHostFree(h->h_status);
+    for (auto &e : h->ev) if (e) hipEventDestroy(e);
+    if (h->stream) hipStreamDestroy(h->stream);
+    delete h;
+}
+
+extern "C" int orbx_create(orbx_extractor **out, int nfeatures, float scale_factor, int nlevels,
+                           int ini_th, int min_th, int device, int max_width, int max_height, int max_batch)
+{
+    if (!out) return fail(ORBX_E_INVALID, "out is NULL");
+    *out = nullptr;
+    if (nfeatures < 0 || nlevels < 1 || nlevels > ORBX_MAX_LEVELS || !(scale_factor > 1.0f) ||
+        max_width < 1 || max_height < 1 || max_batch < 1)
+        return fail(ORBX_E_INVALID, "bad constructor argument (nfeatures=%d scale=%g nlevels=%d max=%dx%dx%d)",
+                    nfeatures, scale_factor, nlevels, max_width, max_height, max_batch);
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+        return fail(ORBX_E_HIP, "no HIP device: liborbx has no CPU path");
+    if (device < 0 || device >= ndev) return fail(ORBX_E_INVALID, "device %d of %d", device, ndev);
+    HIPCHK(hipSetDevice(device));
+
+    orbx_extractor *h = new orbx_extractor();
+    h->nfeatures = nfeatures; h->scale_factor = scale_factor; h->nlevels = nlevels;
+    h->ini_th = std::min(std::max(ini_th, 0), 255); h->min_th = std::min(std::max(min_th, 0), 255);
+    h->device = device; h->max_w = max_width; h->max_h = max_height; h->max_batch = max_batch;
+    memset(&h->work, 0, sizeof(h->work));
+    build_tables(h);
+
+    std::string why;
+    int rc = make_plan(h, max_width, max_height, &h->max_plan, &why);
+    if (rc != ORBX_OK) { delete h; return fail(rc, "max shape %dx%d: %s", max_width, max_height, why.c_str()); }
+    int max_list = 0;
+    for (int l = 0; l < nlevels; l++) max_list = std::max(max_list, h->max_plan.lv[l].list_cap);
+    h->oct_lds = orbx_octree_lds_bytes(std::max(max_list, 8));
+    if (h->oct_lds > 150 * 1024) { delete h; return fail(ORBX_E_INVALID, "nfeatures=%d needs %zu B of LDS for the quadtree (max 153600)", nfeatures, h->oct_lds); }
+
+#define ALLOC(ptr, bytes)                                                                       \
+    do {                                                                                        \
+        hipError_t e_ = hipMalloc((void **)&(ptr), std::max<size_t>((bytes), 256));             \
+        if (e_ != hipSuccess) { free_all(h); return fail(ORBX_E_HIP, "hipMalloc(%s, %zu): %s", #ptr, (size_t)(bytes), hipGetErrorString(e_)); } \
+    } while (0)
+    const size_t B = (size_t)max_batch;
+    h->in_stride = (int)align_up(max_width, 64);
+    h->in_frame = align_up((size_t)h->in_stride * max_height, 256);
+    ALLOC(h->d_input, B * h->in_frame);
+    size_t off = 0, tab_e = 0;
+    for (int l = 1; l < nlevels; l++) {
+        const OrbxLevel &L = h->max_plan.lv[l];
+        h->pyr_level_off[l] = off;
+        off += B * align_up(align_up(L.w, 64) * (size_t)L.h, 256);
+        tab_e += (size_t)L.w + L.h;
+    }
+    h->pyr_bytes = off; h->tab_elems = tab_e;
+    ALLOC(h->d_pyr, off);
+    ALLOC(h->d_tab_i, tab_e * sizeof(int));
+    ALLOC(h->d_tab_s, tab_e * sizeof(short2));
+    const OrbxPlan &M = h->max_plan;
+    ALLOC(h->work.cand, B * M.cand_frame * sizeof(OrbxCand));
+    ALLOC(h->work.owner, B * M.cand_frame * sizeof(uint32_t));
+    ALLOC(h->work.arena, B * M.arena_frame * sizeof(OrbxNode));
+    ALLOC(h->work.sel, B * M.list_frame * sizeof(OrbxCand));
+    ALLOC(h->work.cand_count, B * ORBX_MAX_LEVELS * sizeof(uint32_t));
+    ALLOC(h->work.nk, B * ORBX_MAX_LEVELS * sizeof(uint32_t));
+    ALLOC(h->work.errflags, B * sizeof(uint32_t));
+    ALLOC(h->d_kps, B * M.out_cap * sizeof(orbx_keypoint));
+    ALLOC(h->d_desc, B * M.out_cap * 32);
+    ALLOC(h->d_counts, B * sizeof(int32_t));
+    ALLOC(h->d_status, B * sizeof(int32_t));
+#undef ALLOC
+    if (hipHostMalloc((void **)&h->h_kps, B * M.out_cap * sizeof(orbx_keypoint)) != hipSuccess ||
+        hipHostMalloc((void **)&h->h_desc, B * M.out_cap * 32) != hipSuccess ||
+        hipHostMalloc((void **)&h->h_counts, B * sizeof(int32_t)) != hipSuccess ||
+        hipHostMalloc((void **)&h->h_status, B * sizeof(int32_t)) != hipSuccess) {
+        free_all(h);
+        return fail(ORBX_E_HIP, "hipHostMalloc failed");
+    }
+    if (hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess) { free_all(h); return fail(ORBX_E_HIP, "hipStreamCreate failed"); }
+    for (auto &e : h->ev) if (hipEventCreate(&e) != hipSuccess) { free_all(h); return fail(ORBX_E_HIP, "hipEventCreate failed"); }
+    if (orbx_upload_constants(h->umax, h->gauss_k) != 0) { free_all(h); return fail(ORBX_E_HIP, "constant upload failed"); }
+    *out = h;
+    return ORBX_OK;
+}
+
+extern "C" void orbx_destroy(orbx_extractor *h) { free_all(h); }
+
+extern "C" int orbx_set_option(orbx_extractor *h, int option, int value)
+{
+    if (!h) return fail(ORBX_E_INVALID, "NULL handle");
+    if (option == ORBX_OPT_BLUR_ROUNDING && (value == 0 || value == 1)) { h->blur_mode = value; h->plan.blur_mode = value; return ORBX_OK; }
+    return fail(ORBX_E_INVALID, "unknown option %d=%d", option, value);
+}
+extern "C" int orbx_get_levels(const orbx_extractor *h) { return h ? h->nlevels : 0; }
+extern "C" float orbx_get_scale_factor(const orbx_extractor *h) { return h ? h->scale_factor : 0.f; }
+extern "C" int orbx_get_tables(const orbx_extractor *h, float *sf, float *isf, float *s2, float *is2)
+{
+    if (!h) return fail(ORBX_E_INVALID, "NULL handle");
+    for (int i = 0; i < h->nlevels; i++) {
+        if (sf) sf[i] = h->scale[i];
+        if (isf) isf[i] = h->inv_scale[i];
+        if (s2) s2[i] = h->sigma2[i];
+        if (is2) is2[i] = h->inv_sigma2[i];
+    }
+    return ORBX_OK;
+}
+extern "C" int orbx_get_features_per_level(const orbx_extractor *h, int *q)
+{
+    if (!h || !q) return fail(ORBX_E_INVALID, "NULL argument");
+    for (int i = 0; i < h->nlevels; i++) q[i] = h->quota[i];
+    return ORBX_OK;
+}
+extern "C" int orbx_capacity(const orbx_extractor *h) { return h ? h->max_plan.out_cap : 0; }
+extern "C" int orbx_set_profiling(orbx_extractor *h, int enabled) { if (!h) return ORBX_E_INVALID; h->profiling = enabled != 0; return ORBX_OK; }
+extern "C" int orbx_last_stage_ms(orbx_extractor *h, float ms[4])
+{
+    if (!h || !ms) return fail(ORBX_E_INVALID, "NULL argument");
+    memcpy(ms, h->stage_ms, sizeof(float) * 4);
+    return ORBX_OK;
+}
+
+// (re)plan for a frame shape; buffers stay those sized at create
+static int ensure_plan(orbx_extractor *h, int W, int H)
+{
+    if (W == h->cur_w && H == h->cur_h) return ORBX_OK;
+    if (W > h->max_w || H > h->max_h) return fail(ORBX_E_SHAPE, "frame %dx%d exceeds the handle's max %dx%d", W, H, h->max_w, h->max_h);
+    OrbxPlan P;
+    std::string why;
+    int rc = make_plan(h, W, H, &P, &why);
+    if (rc != ORBX_OK) return fail(rc, "frame %dx%d: %s", W, H, why.c_str());
+    const OrbxPlan &M = h->max_plan;
+    // keep the allocation layout of the max plan (offsets/capacities) so every shape fits
+    for (int l = 0; l < h->nlevels; l++) {
+        OrbxLevel &L = P.lv[l];
+        const OrbxLevel &X = M.lv[l];
+        if (L.cand_cap > X.cand_cap || L.list_cap > X.list_cap || L.arena_cap > X.arena_cap || L.w > X.w || L.h > X.h)
+            return fail(ORBX_E_SHAPE, "frame %dx%d level %d does not fit the workspace planned for %dx%d", W, H, l, h->max_w, h->max_h);
+        L.cand_off = X.cand_off; L.list_off = X.list_off; L.arena_off = X.arena_off;
+        if (L.nCols > 0) { L.cand_cap = X.cand_cap; L.arena_cap = X.arena_cap; }
+    }
+    P.cand_frame = M.cand_frame; P.list_frame = M.list_frame; P.arena_frame = M.arena_frame; P.out_cap = M.out_cap;
+
+    std::vector<int> ti(h->tab_elems ? h->tab_elems : 1);
+    std::vector<short2> ts(h->tab_elems ? h->tab_elems : 1);
+    size_t e = 0;
+    for (int l = 1; l < h->nlevels; l++) {
+        OrbxLevel &L = P.lv[l];
+        L.stride = (int)align_up(L.w, 64);
+        L.frame_stride = (long long)align_up((size_t)L.stride * L.h, 256);
+        L.base = h->d_pyr + h->pyr_level_off[l];
+        const OrbxLevel &S = P.lv[l - 1];
+        plan_resize(S.w, S.h, L.w, L.h, &ti[e], &ts[e], &ti[e + L.w], &ts[e + L.w], &h->area2[l]);
+        h->tabs[l].xofs = h->d_tab_i + e; h->tabs[l].alpha = h->d_tab_s + e;
+        h->tabs[l].yofs = h->d_tab_i + e + L.w; h->tabs[l].beta = h->d_tab_s + e + L.w;
+        e += (size_t)L.w + L.h;
+    }
+    HIPCHK(hipStreamSynchronize(h->stream));
+    HIPCHK(hipMemcpy(h->d_tab_i, ti.data(), e * sizeof(int), hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(h->d_tab_s, ts.data(), e * sizeof(short2), hipMemcpyHostToDevice));
+    h->plan = P;
+    h->cur_w = W; h->cur_h = H;
+    return ORBX_OK;
+}
+
+// enqueue the whole pipeline for `nframes` frames already resident in HBM
+static int enqueue(orbx_extractor *h, const uint8_t *d_images, int nframes, int W, int H, int row_stride,
+                   long long frame_stride, orbx_keypoint *d_kps, uint8_t *d_desc, int32_t *d_counts,
+                   int32_t *d_status, hipStream_t s)
+{
+    int rc = ensure_plan(h, W, H);
+    if (rc != ORBX_OK) return rc;
+    OrbxPlan &P = h->plan;
+    P.blur_mode = h->blur_mode;
+    P.lv[0].base = const_cast<uint8_t *>(d_images);
+    P.lv[0].stride = row_stride;
+    P.lv[0].frame_stride = frame_stride;
+    h->last_input = d_images; h->last_in_stride = row_stride; h->last_in_frame = frame_stride; h->last_batch = nframes;
+
+    const bool prof = h->profiling != 0;
+    HIPCHK(hipMemsetAsync(h->work.cand_count, 0, (size_t)nframes * h->nlevels * sizeof(uint32_t), s));
+    HIPCHK(hipMemsetAsync(h->work.errflags, 0, (size_t)nframes * sizeof(uint32_t), s));
+    if (prof) HIPCHK(hipEventRecord(h->ev[0], s));
+    for (int l = 1; l < h->nlevels; l++) orbx_launch_resize(P.lv[l - 1], P.lv[l], h->tabs[l], h->area2[l], nframes, s);
+    if (prof) HIPCHK(hipEventRecord(h->ev[1], s));
+    orbx_launch_fast(P, h->work, nframes, s);
+    if (prof) HIPCHK(hipEventRecord(h->ev[2], s));
+    orbx_launch_octree(P, h->work, nframes, h->oct_lds, s);
+    if (prof) HIPCHK(hipEventRecord(h->ev[3], s));
+    orbx_launch_describe(P, h->work, nframes, d_kps, d_desc, d_counts, d_status, s);
+    if (prof) HIPCHK(hipEventRecord(h->ev[4], s));
+    HIPCHK(hipGetLastError());
+    return ORBX_OK;
+}
+
+static int finish_profile(orbx_extractor *h)
+{
+    if (!h->profiling) return ORBX_OK;
+    HIPCHK(hipEventSynchronize(h->ev[4]));
+    for (int i = 0; i < 4; i++) HIPCHK(hipEventElapsedTime(&h->stage_ms[i], h->ev[i], h->ev[i + 1]));
+    return ORBX_OK;
+}
+
+extern "C" int orbx_extract_batch_device(orbx_extractor *h, const uint8_t *d_images, int nframes, int width,
+                                         int height, int row_stride, size_t frame_stride,
+                                         orbx_keypoint *d_keypoints, uint8_t *d_descriptors, int cap,
+                                         int32_t *d_counts, int32_t *d_status, void *hip_stream)
+{
+    if (!h) return fail(ORBX_E_INVALID, "NULL handle");
+    if (!d_images || !d_keypoints || !d_descriptors || !d_counts || !d_status) return fail(ORBX_E_INVALID, "NULL device pointer");
+    if (nframes < 1 || nframes > h->max_batch) return fail(ORBX_E_INVALID, "nframes=%d (max_batch=%d)", nframes, h->max_batch);
+    if (width < 1 || height < 1 || row_stride < width) return fail(ORBX_E_INVALID, "bad frame geometry %dx%d stride %d", width, height, row_stride);
+    if (cap != h->max_plan.out_cap) return fail(ORBX_E_CAPACITY, "device outputs must be laid out with cap == orbx_capacity() == %d (got %d)", h->max_plan.out_cap, cap);
+    HIPCHK(hipSetDevice(h->device));
+    hipStream_t s = hip_stream ? (hipStream_t)hip_stream : h->stream;
+    int rc = enqueue(h, d_images, nframes, width, height, row_stride, (long long)frame_stride, d_keypoints,
+                     d_descriptors, d_counts, d_status, s);
+    if (rc != ORBX_OK) return rc;
+    if (h->profiling) return finish_profile(h);
+    return ORBX_OK;
+}
+
+extern "C" int orbx_extract_batch(orbx_extractor *h, const uint8_t *images, int nframes, int width, int height,
+                                  int row_stride, size_t frame_stride, orbx_keypoint *keypoints,
+                                  uint8_t *descriptors, int cap, int *counts)
+{
+    if (!h) return fail(ORBX_E_INVALID, "NULL handle");
+    if (!counts) return fail(ORBX_E_INVALID, "counts is NULL");
+    for (int k = 0; k < std::max(nframes, 0); k++) counts[k] = 0;
+    if (!images || width <= 0 || height <= 0 || nframes <= 0) return ORBX_OK;   // :1048 empty image: silent return
+    if (!keypoints || !descriptors) return fail(ORBX_E_INVALID, "NULL output buffer");
+    if (nframes > h->max_batch) return fail(ORBX_E_INVALID, "nframes=%d (max_batch=%d)", nframes, h->max_batch);
+    if (row_stride < width) return fail(ORBX_E_INVALID, "row_stride %d < width %d", row_stride, width);
+    if (width > h->max_w || height > h->max_h) return fail(ORBX_E_SHAPE, "frame %dx%d exceeds the handle's max %dx%d", width, height, h->max_w, h->max_h);
+    HIPCHK(hipSetDevice(h->device));
+    hipStream_t s = h->stream;
+    const int ocap = h->max_plan.out_cap;
+    for (int k = 0; k < nframes; k++)
+        HIPCHK(hipMemcpy2DAsync(h->d_input + (size_t)k * h->in_frame, h->in_stride, images + (size_t)k * frame_stride,
+                                row_stride, width, height, hipMemcpyHostToDevice, s));
+    int rc = enqueue(h, h->d_input, nframes, width, height, h->in_stride, (long long)h->in_frame, h->d_kps, h->d_desc,
+                     h->d_counts, h->d_status, s);
+    if (rc != ORBX_OK) return rc;
+    HIPCHK(hipMemcpyAsync(h->h_counts, h->d_counts, sizeof(int32_t) * nframes, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipMemcpyAsync(h->h_status, h->d_status, sizeof(int32_t) * nframes, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipMemcpyAsync(h->h_kps, h->d_kps, sizeof(orbx_keypoint) * (size_t)ocap * nframes, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipMemcpyAsync(h->h_desc, h->d_desc, (size_t)32 * ocap * nframes, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipStreamSynchronize(s));
+    rc = finish_profile(h);
+    if (rc != ORBX_OK) return rc;
+    for (int k = 0; k < nframes; k++) {
+        if (h->h_status[k] != ORBX_OK)
+            return fail(h->h_status[k], "frame %d: device status %d (%s)", k, h->h_status[k],
+                        h->h_status[k] == ORBX_E_CAND_OVERFLOW ? "FAST candidate buffer overflow" :
+                        h->h_status[k] == ORBX_E_TREE_OVERFLOW ? "quadtree arena overflow" : "capacity");
+        const int n = h->h_counts[k];
+        if (n > cap) return fail(ORBX_E_CAPACITY, "frame %d produced %d keypoints, caller capacity %d (use orbx_capacity())", k, n, cap);
+        memcpy(keypoints + (size_t)k * cap, h->h_kps + (size_t)k * ocap, sizeof(orbx_keypoint) * n);
+        memcpy(descriptors + (size_t)k * cap * 32, h->h_desc + (size_t)k * ocap * 32, (size_t)32 * n);
+        counts[k] = n;
+    }
+    return ORBX_OK;
+}
+
+extern "C" int orbx_extract(orbx_extractor *h, const uint8_t *image, int width, int height, int stride,
+                            orbx_keypoint *keypoints, uint8_t *descriptors, int cap, int *n)
+{
+    if (!n) return fail(ORBX_E_INVALID, "n is NULL");
+    return orbx_extract_batch(h, image, 1, width, height, stride, (size_t)stride * (size_t)std::max(height, 0),
+                              keypoints, descriptors, cap, n);
+}
+
+extern "C" int orbx_level_size(const orbx_extractor *h, int level, int *width, int *height)
+{
+    if (!h || level < 0 || level >= h->nlevels || h->cur_w == 0) return fail(ORBX_E_INVALID, "no plan / bad level");
+    if (width) *width = h->plan.lv[level].w;
+    if (height) *height = h->plan.lv[level].h;
+    return ORBX_OK;
+}
+
+static inline int reflect101_host(int p, int len)
+{
+    if (len == 1) return 0;
+    while (p < 0 || p >= len) p = p < 0 ? -p : 2 * (len - 1) - p;
+    return p;
+}
+
+extern "C" int orbx_download_level(orbx_extractor *h, int frame, int level, uint8_t *dst, int dst_stride, int border)
+{
+    if (!h || !dst || level < 0 || level >= h->nlevels || h->cur_w == 0 || frame < 0 || frame >= h->last_batch || border < 0)
+        return fail(ORBX_E_INVALID, "bad download_level argument");
+    HIPCHK(hipSetDevice(h->device));
+    OrbxLevel L = h->plan.lv[level];
+    if (level == 0) { L.base = const_cast<uint8_t *>(h->last_input); L.stride = h->last_in_stride; L.frame_stride = h->last_in_frame; }
+    if (dst_stride < L.w + 2 * border) return fail(ORBX_E_INVALID, "dst_stride too small");
+    HIPCHK(hipStreamSynchronize(h->stream));
+    uint8_t *interior = dst + (size_t)border * dst_stride + border;
+    HIPCHK(hipMemcpy2D(interior, dst_stride, L.base + (size_t)frame * L.frame_stride, L.stride, L.w, L.h, hipMemcpyDeviceToHost));
+    if (border > 0) {   // copyMakeBorder(..., BORDER_REFLECT_101), :1127-1133
+        for (int y = -border; y < L.h + border; y++) {
+            const uint8_t *srow = interior + (ptrdiff_t)reflect101_host(y, L.h) * dst_stride;
+            uint8_t *drow = interior + (ptrdiff_t)y * dst_stride;
+            if (y < 0 || y >= L.h) memcpy(drow, srow, (size_t)L.w);
+            for (int x = 1; x <= border; x++) {
+                drow[-x] = srow[reflect101_host(-x, L.w)];
+                drow[L.w - 1 + x] = srow[reflect101_host(L.w - 1 + x, L.w)];
+            }
+        }
+    }
+    return ORBX_OK;
+}
+
+extern "C" int orbx_download_candidates(orbx_extractor *h, int frame, int level, int32_t *xyr, int cap)
+{
+    if (!h || !xyr || level < 0 || level >= h->nlevels || h->cur_w == 0 || frame < 0 || frame >= h->last_batch)
+        return fail(ORBX_E_INVALID, "bad download_candidates argument");
+    HIPCHK(hipSetDevice(h->device));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    uint32_t n = 0;
+    HIPCHK(hipMemcpy(&n, h->work.cand_count + (size_t)frame * h->nlevels + level, sizeof(n), hipMemcpyDeviceToHost));
+    const OrbxLevel &L = h->plan.lv[level];
+    n = std::min<uint32_t>(n, (uint32_t)L.cand_cap);
+    if ((int)n > cap) return fail(ORBX_E_CAPACITY, "%u candidates, capacity %d", n, cap);
+    std::vector<OrbxCand> tmp(n ? n : 1);
+    HIPCHK(hipMemcpy(tmp.data(), h->work.cand + (size_t)frame * h->plan.cand_frame + L.cand_off, sizeof(OrbxCand) * n, hipMemcpyDeviceToHost));
+    for (uint32_t i = 0; i < n; i++) {
+        xyr[3 * i] = (int32_t)(tmp[i].xy & 0xFFFFu);
+        xyr[3 * i + 1] = (int32_t)(tmp[i].xy >> 16);
+        xyr[3 * i + 2] = (int32_t)tmp[i].resp;
+    }
+    return (int)n;
+}

@@ -1,0 +1,90 @@
+// orbx_internal.h -- shared between the host-side planner (orbx_capi.hip) and the gfx950 kernels.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "../../include/orbx.h"
+
+#define ORBX_EDGE 19          // EDGE_THRESHOLD, src/ORBextractor.cc:76
+#define ORBX_MINB 16          // minBorderX/Y = EDGE_THRESHOLD-3, src/ORBextractor.cc:775
+#define ORBX_HALF_PATCH 15    // src/ORBextractor.cc:75
+
+// FAST cell kernel limits (cell zone <= 59x59: wCell = ceil(width/floor(width/30)) < 60)
+#define FAST_TILE_MAX 66
+#define FAST_TILE_STRIDE 68
+#define FAST_ZONE_MAX 60
+#define FAST_THREADS 256
+
+#define OCT_THREADS 512
+#define OCT_ID_MASK 0x3FFFFFFFu
+
+#define DESC_THREADS 64
+#define DESC_R 18             // rotated rBRIEF sample radius (max |p| = 18.38)
+#define DESC_BL 37            // blurred tile edge  (2*18+1)
+#define DESC_RAW 43           // raw tile edge      (37 + 2*3 for the 7x7 blur)
+
+enum { ERRF_CAND_OVERFLOW = 1, ERRF_TREE_OVERFLOW = 2, ERRF_OUT_OVERFLOW = 4 };
+
+// One FAST candidate: xy = x | y << 16 (absolute level-interior coordinates), resp = corner score
+struct __attribute__((aligned(8))) OrbxCand { uint32_t xy; uint32_t resp; };
+
+// Quadtree node in the global arena (DivideNode boxes, relative to (minBorderX,minBorderY))
+struct __attribute__((aligned(16))) OrbxNode {
+    int16_t x0, y0, x1, y1;   // UL.x, UL.y, UR.x, BR.y
+    int32_t count;            // vKeys.size()
+    int32_t slot;             // per-pass slot (alive nodes) / final list position
+};
+
+struct OrbxLevel {
+    int w, h, stride;             // interior size and row stride in bytes
+    long long frame_stride;       // bytes between frames of this level
+    uint8_t *base;                // frame 0 of this level (level 0: the caller's image)
+    int maxBX, maxBY;             // w-16, h-16
+    int nCols, nRows, wCell, hCell;
+    int cell_begin;               // index of this level's first cell in the per-frame cell list
+    int quota;                    // mnFeaturesPerLevel[level]
+    int nIni;                     // DistributeOctTree root count
+    float hX;                     // root width
+    int cand_cap;  long long cand_off;    // per-frame candidate capacity / element offset
+    int list_cap;  long long list_off;    // quadtree list capacity / element offset (sel buffer)
+    int arena_cap; long long arena_off;   // node arena capacity / element offset
+    float scale;                  // mvScaleFactor[level]
+    float kp_size;                // (float)(int)(31*scale)
+};
+
+struct OrbxPlan {
+    int nlevels;
+    int ini_th, min_th;
+    int ncells;                   // cells per frame over all levels
+    int blur_mode;
+    int out_cap;                  // per-frame output capacity
+    long long cand_frame;         // candidates per frame (elements)
+    long long list_frame;         // sel entries per frame
+    long long arena_frame;        // arena nodes per frame
+    OrbxLevel lv[ORBX_MAX_LEVELS];
+};
+
+struct OrbxWork {                 // device workspace pointers (per handle)
+    OrbxCand *cand;               // [B][cand_frame]
+    uint32_t *cand_count;         // [B][L]
+    uint32_t *owner;              // [B][cand_frame]  quadtree: key -> node id (| quadrant << 30)
+    OrbxNode *arena;              // [B][arena_frame]
+    OrbxCand *sel;                // [B][list_frame]  selected keypoints per level, list order
+    uint32_t *nk;                 // [B][L]           selected per level
+    uint32_t *errflags;           // [B]
+};
+
+struct ResizeTab {                // per destination level
+    const int *xofs; const short2 *alpha; const int *yofs; const short2 *beta;
+};
+
+// ---- launchers (orbx_kernels.hip) ----
+void orbx_launch_resize(const OrbxLevel &src, const OrbxLevel &dst, const ResizeTab &tab, int area2,
+                        int nframes, hipStream_t s);
+void orbx_launch_fast(const OrbxPlan &plan, const OrbxWork &wk, int nframes, hipStream_t s);
+void orbx_launch_octree(const OrbxPlan &plan, const OrbxWork &wk, int nframes, size_t lds_bytes,
+                        hipStream_t s);
+void orbx_launch_describe(const OrbxPlan &plan, const OrbxWork &wk, int nframes,
+                          orbx_keypoint *d_kps, uint8_t *d_desc, int32_t *d_counts,
+                          int32_t *d_status, hipStream_t s);
+size_t orbx_octree_lds_bytes(int list_cap_max);
+int orbx_upload_constants(const int umax[16], const int gauss_k[7]);
