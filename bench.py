@@ -1,0 +1,254 @@
+#!/usr/bin/env python3
+"""bench.py -- ORB extract(+match) throughput on MI355X, BASELINE.json's metric.
+
+One step = one pass of the hot path over one batch of synthetic frames that are already resident in
+HBM: 8-level pyramid -> per-cell FAST -> quadtree -> orientation + blur + rBRIEF for every frame of
+the batch, then best/second-best Hamming matching of every frame against its predecessor, all
+through the C ABI of my-slam_amd/lib/liborbx.so.  With --gpus N (launched by torch.distributed.run,
+one rank per GPU) every rank processes its own batch (weak scaling: frames are independent units,
+no data-path collective) and RCCL over xGMI only gathers the keypoint/descriptor buffers to rank 0.
+
+Prints ONE JSON line on rank 0 (contract in the task prompt): value = keypoints/s over all ranks.
+"""
+import argparse
+import importlib.util
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+
+
+def load_pkg():
+    if "my_slam_amd" in sys.modules:
+        return sys.modules["my_slam_amd"]
+    spec = importlib.util.spec_from_file_location(
+        "my_slam_amd", os.path.join(ROOT, "my-slam_amd", "__init__.py"),
+        submodule_search_locations=[os.path.join(ROOT, "my-slam_amd")])
+    mod = importlib.util.module_from_spec(spec)
+    sys.modules["my_slam_amd"] = mod
+    spec.loader.exec_module(mod)
+    return mod
+
+
+def level_geometry(W, H, nlevels=8, scale=1.2):
+    sf = np.float32(1.0)
+    out = []
+    for l in range(nlevels):
+        inv = np.float32(1.0) / sf
+        out.append((int(np.rint(np.float32(W) * inv)), int(np.rint(np.float32(H) * inv))))
+        sf = np.float32(sf * np.float32(scale))
+    return out
+
+
+def algorithmic_bytes(W, H, nlevels, n_kp, n_cand, n_q, n_t):
+    """SURVEY.md 8(d) B_extract = 5P - px_last + 1321 N, split per stage (DESIGN.md 'Kernels')."""
+    lv = level_geometry(W, H, nlevels)
+    px = [w * h for (w, h) in lv]
+    P = sum(px)
+    return {
+        "pyramid": W * H + (P - px[-1]) + (P - px[0]),
+        "fast": P,
+        "quadtree": 12 * n_cand + 8 * n_kp,            # not in the survey's formula: candidates in, keypoints out
+        "describe": 2 * P + n_kp * (749 + 512 + 32 + 28),
+        "match": (n_q + n_t) * 32 + n_q * 12,
+    }
+
+
+def cpu_baseline(frames, nfeatures, budget_s=12.0):
+    """Oracle (CPU restatement, -O3 -march=native, 1 thread) on a bounded sample of the same frames."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle_lib as O
+    ex = O.Extractor(nfeatures, native=True)
+    t0 = time.perf_counter()
+    nk = 0
+    nf = 0
+    prev = None
+    while True:
+        img = frames[nf % len(frames)]
+        kps, desc, _ = ex.extract(img)
+        if prev is not None:
+            O.match_dense(desc, kps["angle"], prev[1], prev[0]["angle"], 50, 0.9, True)
+        prev = (kps, desc)
+        nk += len(kps)
+        nf += 1
+        el = time.perf_counter() - t0
+        if el > budget_s or nf >= 4096:
+            break
+    return {"value": nk / el, "unit": "keypoints/s", "cores": 1, "kind": "port",
+            "sample": "%d frames (extract + match vs previous frame) in %.1f s, 1 thread, oracle -O3 -march=native -ffp-contract=off; %.2f frames/s"
+                      % (nf, el, nf / el),
+            "host_cpus": os.cpu_count()}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--width", type=int, default=640)
+    ap.add_argument("--height", type=int, default=480)
+    ap.add_argument("--nfeatures", type=int, default=1000)
+    ap.add_argument("--batch", type=int, default=64, help="frames per GPU per step")
+    ap.add_argument("--no-match", action="store_true")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-budget", type=float, default=12.0)
+    args = ap.parse_args()
+
+    import torch
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: liborbx has no CPU path")
+    torch.cuda.set_device(local)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+
+    pkg = load_pkg()
+    import my_slam_amd.synth as synth
+    W, H, B, NF = args.width, args.height, args.batch, args.nfeatures
+    do_match = not args.no_match and B > 1
+
+    # synthetic TUM-mono-like stream, a different canvas per rank
+    frames_np = synth.stream(4 + rank, W, H, B)
+    frames = torch.from_numpy(frames_np).cuda()
+    ex = pkg.ORBextractor(NF, 1.2, 8, 20, 7, device=local, max_width=W, max_height=H, max_batch=B)
+    cap = ex.cap
+    kps = torch.zeros((B, cap, 7), dtype=torch.float32, device="cuda")
+    desc = torch.zeros((B, cap, 32), dtype=torch.uint8, device="cuda")
+    counts = torch.zeros(B, dtype=torch.int32, device="cuda")
+    status = torch.zeros(B, dtype=torch.int32, device="cuda")
+    matcher = pkg.ORBmatcher(0.9, True, device=local, max_queries=cap, max_train=cap, max_pairs=1) if do_match else None
+    match12 = torch.full((B, cap), -1, dtype=torch.int32, device="cuda")
+    nmatch = torch.zeros(B, dtype=torch.int32, device="cuda")
+    gather_bufs = None
+    if world > 1 and rank == 0:
+        gather_bufs = ([torch.empty_like(kps) for _ in range(world)], [torch.empty_like(desc) for _ in range(world)],
+                       [torch.empty_like(counts) for _ in range(world)])
+
+    def step():
+        s = torch.cuda.current_stream().cuda_stream
+        ex.extract_batch_device(frames.data_ptr(), B, W, H, frames.stride(1), frames.stride(0),
+                                kps.data_ptr(), desc.data_ptr(), counts.data_ptr(), status.data_ptr(), s)
+        if do_match:   # frame k (query) against frame k-1 (train), k = 1..B-1
+            matcher.match_batch_device(desc.data_ptr() + cap * 32, kps.data_ptr() + cap * 28, counts.data_ptr() + 4,
+                                       desc.data_ptr(), kps.data_ptr(), counts.data_ptr(), cap, B - 1,
+                                       match12.data_ptr() + cap * 4, nmatch.data_ptr() + 4, stream=s)
+        if world > 1:  # RCCL over xGMI: results back to rank 0, nothing else crosses GPUs
+            dist.gather(kps, gather_bufs[0] if rank == 0 else None, dst=0)
+            dist.gather(desc, gather_bufs[1] if rank == 0 else None, dst=0)
+            dist.gather(counts, gather_bufs[2] if rank == 0 else None, dst=0)
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    if int(status.abs().sum().item()) != 0:
+        raise SystemExit("device status nonzero: %s" % status.tolist())
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    nk_local = int(counts.sum().item())
+    nm_local = int(nmatch.sum().item()) if do_match else 0
+    tot = torch.tensor([nk_local, nm_local], dtype=torch.int64, device="cuda")
+    if world > 1:
+        dist.all_reduce(tot)
+    nk_all, nm_all = int(tot[0].item()), int(tot[1].item())
+
+    # ---- per-stage GPU time (HIP events on the launch stream, inside the library) ----
+    roof = None
+    stage = {}
+    if rank == 0:
+        ex.set_profiling(True)
+        acc = np.zeros(4)
+        tm = 0.0
+        reps = max(3, min(10, args.steps))
+        for _ in range(reps):
+            s = torch.cuda.current_stream().cuda_stream
+            ex.extract_batch_device(frames.data_ptr(), B, W, H, frames.stride(1), frames.stride(0),
+                                    kps.data_ptr(), desc.data_ptr(), counts.data_ptr(), status.data_ptr(), s)
+            acc += ex.stage_ms()
+            if do_match:
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                matcher.match_batch_device(desc.data_ptr() + cap * 32, kps.data_ptr() + cap * 28, counts.data_ptr() + 4,
+                                           desc.data_ptr(), kps.data_ptr(), counts.data_ptr(), cap, B - 1,
+                                           match12.data_ptr() + cap * 4, nmatch.data_ptr() + 4, stream=s)
+                e1.record()
+                torch.cuda.synchronize()
+                tm += e0.elapsed_time(e1)
+        ex.set_profiling(False)
+        acc /= reps
+        stage = {"pyramid": acc[0], "fast": acc[1], "quadtree": acc[2], "describe": acc[3]}
+        if do_match:
+            stage["match"] = tm / reps
+        ncand = sum(len(ex.candidates(0, l)) for l in range(8))   # frame 0's candidates, representative
+        nkf = nk_local / B
+        ab = algorithmic_bytes(W, H, 8, nkf, ncand, nkf, nkf)
+        dom = max(stage, key=lambda k: stage[k])
+        nunits = (B - 1) if dom == "match" else B
+        achieved = ab[dom] * nunits / (stage[dom] * 1e-3) / 1e9
+        traffic = None
+        tf = os.path.join(ROOT, "profiles", "traffic.json")
+        if os.path.exists(tf):
+            try:
+                traffic = json.load(open(tf)).get(dom)
+            except Exception:
+                traffic = None
+        roof = {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 2), "peak": 8000.0, "unit": "GB/s",
+                "frac": round(achieved / 8000.0, 5), "traffic": traffic,
+                "algorithmic_bytes_per_launch": int(ab[dom] * nunits),
+                "avg_launch_ms": round(stage[dom], 4),
+                "stage_ms": {k: round(float(v), 4) for k, v in stage.items()},
+                "whole_path_algorithmic_GBps": round(sum(ab[k] for k in ("pyramid", "fast", "describe")) * B * world
+                                                     / (elapsed / args.steps) / 1e9, 2)}
+
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        cpu = cpu_baseline(frames_np, NF, args.cpu_budget)
+
+    if rank == 0:
+        ms = elapsed / args.steps * 1e3
+        out = {
+            "metric": "ORB keypoints/s + frames/s, 1000 feats/frame @640x480, 1/2/4/8 GPU",
+            "value": round(nk_all / (elapsed / args.steps), 1),
+            "unit": "keypoints/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(ms, 4), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "u8", "data": "synthetic",
+            "frames_per_s": round(B * world / (elapsed / args.steps), 1),
+            "matches_per_step": nm_all,
+            "keypoints_per_frame": round(nk_all / (B * world), 2),
+            "config": {"workload": "%dx%d nFeatures=%d 8 levels scale 1.2 (BASELINE configs[1] shape), batch of %d frames per GPU "
+                                   "(configs[3] stream), extract%s; inputs resident in HBM"
+                                   % (W, H, NF, B, " + dense match vs previous frame (ratio 0.9, TH_LOW, rotation filter)" if do_match else ""),
+                       "frames_per_gpu": B, "width": W, "height": H, "nfeatures": NF,
+                       "parallelism": "frames sharded over %d GPU(s); RCCL gather of keypoint/descriptor buffers to rank 0" % world},
+            "roofline": roof,
+            "cpu_baseline": cpu,
+        }
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,94 @@
+/*
+ * orbm.h -- C ABI of the MI355X-native ORB descriptor matcher primitives (liborbx.so).
+ *
+ * Drop-in boundary for the Hamming inner loops of the reference's ORB_SLAM2::ORBmatcher
+ * (citations relative to WChen09/My-SLAM):
+ *   include/ORBmatcher.h:44, src/ORBmatcher.cc:1647-1663   static DescriptorDistance(a, b)
+ *   src/ORBmatcher.cc:201-232 (SearchByBoW), :432-471 (SearchForInitialization), :76-125, :370-398,
+ *   :1397-1430, :1535-1558 (SearchByProjection), :715-756 (SearchForTriangulation), :901-949,
+ *   :1060-1079 (Fuse), :1199-1219, :1279-1299 (SearchBySim3), src/Frame.cc:522-549 (stereo):
+ *       every one is "best / second-best DescriptorDistance over a candidate index list".
+ *   src/ORBmatcher.cc:1601-1642 ComputeThreeMaxima + the 30-bin rotation histogram (:236-246).
+ * The reference has no whole-frame brute-force matcher: dense N x M matching is the
+ * degenerate case "one candidate list = every train descriptor".
+ *
+ * The geometry / MapPoint bookkeeping around these loops stays host C++ in the caller
+ * (my-slam_amd/host/ORBmatcher.h shows the adapter); the variants whose skip predicates depend on
+ * earlier matches (e.g. :444-445) take the per-candidate distances from orbm_distances() and run
+ * their tiny selection loop on the host, so their results stay identical.
+ *
+ * Descriptors are rows of 32 bytes (cv::Mat N x 32 CV_8U, contiguous).  All functions return 0 or
+ * a negative orbx_status (orbx.h); text via orbm_last_error().  A matcher handle owns a HIP stream
+ * and staging buffers; handles are independent, one handle is not re-entrant.
+ */
+#ifndef ORBM_H
+#define ORBM_H
+
+#include <stddef.h>
+#include <stdint.h>
+#include "orbx.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ORBM_TH_HIGH 100      /* src/ORBmatcher.cc:37 */
+#define ORBM_TH_LOW 50        /* src/ORBmatcher.cc:38 */
+#define ORBM_HISTO_LENGTH 30  /* src/ORBmatcher.cc:39 */
+
+typedef struct orbm_matcher orbm_matcher;
+
+int orbm_create(orbm_matcher **out, int device, int max_queries, int max_train, int max_pairs);
+void orbm_destroy(orbm_matcher *m);
+
+/* ORBmatcher::DescriptorDistance for one pair (host popcount; one pair is not GPU work). */
+int orbm_distance(const uint8_t a[32], const uint8_t b[32]);
+
+/*
+ * best / second-best over candidate lists, on the GPU.  Host buffers.
+ *   cand_off[nq+1], cand_idx[cand_off[nq]] : CSR lists of train indices per query, scanned in list
+ *   order; cand_off == NULL means dense (each query against train 0..nt-1).
+ * Semantics of src/ORBmatcher.cc:201-226: bestDist1 = bestDist2 = 256, bestIdx = -1; strict '<'
+ * updates (first candidate wins a tie; a tie with the best becomes the second best).
+ */
+int orbm_best2(orbm_matcher *m, const uint8_t *q, int nq, const uint8_t *t, int nt,
+               const int32_t *cand_off, const int32_t *cand_idx,
+               int32_t *best_idx, int32_t *best_d, int32_t *second_d);
+
+/* Per-candidate distances dist[cand_off[nq]] (dense: dist[nq*nt], row-major) for the search
+ * variants whose skip predicates interleave with the scan. */
+int orbm_distances(orbm_matcher *m, const uint8_t *q, int nq, const uint8_t *t, int nt,
+                   const int32_t *cand_off, const int32_t *cand_idx, int32_t *dist);
+
+/*
+ * Device-resident, batched, dense: pair b matches d_q[b] (d_nq[b] rows) against d_t[b] (d_nt[b]
+ * rows); descriptor blocks are [nbatch][cap][32] as written by orbx_extract_batch_device, counts
+ * live on the device.  Outputs [nbatch][cap].  Asynchronous on hip_stream (NULL = handle stream).
+ */
+int orbm_best2_batch_device(orbm_matcher *m, const uint8_t *d_q, const int32_t *d_nq,
+                            const uint8_t *d_t, const int32_t *d_nt, int cap, int nbatch,
+                            int32_t *d_best_idx, int32_t *d_best_d, int32_t *d_second_d,
+                            void *hip_stream);
+
+/*
+ * Same plus the SearchByBoW acceptance (:228-232: best <= th and best < nnratio * second) and the
+ * rotation-consistency filter (:236-246, :266-284) using the keypoints' angles.  d_match12[b][i] =
+ * train index or -1; d_nmatches[b] = surviving matches.  BASELINE config 3's "match against the
+ * previous frame".
+ */
+int orbm_match_batch_device(orbm_matcher *m, const uint8_t *d_q, const orbx_keypoint *d_kq,
+                            const int32_t *d_nq, const uint8_t *d_t, const orbx_keypoint *d_kt,
+                            const int32_t *d_nt, int cap, int nbatch, int th, float nnratio,
+                            int check_orientation, int32_t *d_match12, int32_t *d_nmatches,
+                            void *hip_stream);
+
+/* Host helpers: ComputeThreeMaxima (ind[3], -1 = none) and the histogram cull over match12. */
+int orbm_three_maxima(const int32_t *hist_sizes, int L, int32_t ind[3]);
+int orbm_rot_filter(const float *angle_q, const float *angle_t, int32_t *match12, int nq);
+
+const char *orbm_last_error(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -230,3 +230,75 @@ def debug_sincos(theta):
     s = np.empty_like(theta)
     _chk(lib().orbx_debug_sincos(_p(theta), _p(c), _p(s), len(theta)))
     return c, s
+
+
+def _mchk(rc):
+    if rc != ORBX_OK:
+        raise OrbxError(rc, lib().orbm_last_error().decode())
+
+
+class ORBmatcher:
+    """Python mirror of the Hamming primitives of ORB_SLAM2::ORBmatcher (include/ORBmatcher.h:41-89)."""
+    TH_HIGH, TH_LOW, HISTO_LENGTH = 100, 50, 30
+
+    def __init__(self, nnratio=0.6, checkOri=True, device=0, max_queries=8192, max_train=8192, max_pairs=1 << 22):
+        self.L = lib()
+        self.mfNNratio, self.mbCheckOrientation = float(nnratio), bool(checkOri)
+        self.h = C.c_void_p()
+        _mchk(self.L.orbm_create(C.byref(self.h), device, max_queries, max_train, max_pairs))
+
+    def close(self):
+        if getattr(self, "h", None) is not None and self.h:
+            self.L.orbm_destroy(self.h)
+            self.h = None
+
+    __del__ = close
+
+    @staticmethod
+    def DescriptorDistance(a, b):
+        a = np.ascontiguousarray(a, np.uint8)
+        b = np.ascontiguousarray(b, np.uint8)
+        return lib().orbm_distance(_p(a), _p(b))
+
+    def best2(self, q, t, cand_off=None, cand_idx=None):
+        q = np.ascontiguousarray(q, np.uint8).reshape(-1, 32)
+        t = np.ascontiguousarray(t, np.uint8).reshape(-1, 32)
+        nq, nt = len(q), len(t)
+        bi, bd, sd = (np.full(nq, -1, np.int32), np.full(nq, 256, np.int32), np.full(nq, 256, np.int32))
+        if cand_off is not None:
+            cand_off = np.ascontiguousarray(cand_off, np.int32)
+            cand_idx = np.ascontiguousarray(cand_idx, np.int32)
+        _mchk(self.L.orbm_best2(self.h, _p(q), nq, _p(t), nt, _p(cand_off), _p(cand_idx), _p(bi), _p(bd), _p(sd)))
+        return bi, bd, sd
+
+    def distances(self, q, t, cand_off=None, cand_idx=None):
+        q = np.ascontiguousarray(q, np.uint8).reshape(-1, 32)
+        t = np.ascontiguousarray(t, np.uint8).reshape(-1, 32)
+        nq, nt = len(q), len(t)
+        if cand_off is not None:
+            cand_off = np.ascontiguousarray(cand_off, np.int32)
+            cand_idx = np.ascontiguousarray(cand_idx, np.int32)
+            out = np.zeros(int(cand_off[-1]), np.int32)
+        else:
+            out = np.zeros(nq * nt, np.int32)
+        _mchk(self.L.orbm_distances(self.h, _p(q), nq, _p(t), nt, _p(cand_off), _p(cand_idx), _p(out)))
+        return out
+
+    def match_dense(self, q, kq, t, kt, th=None):
+        """Dense SearchByBoW-style acceptance + rotation filter on host buffers (via best2)."""
+        bi, bd, sd = self.best2(q, t)
+        th = self.TH_LOW if th is None else th
+        m = np.where((bd <= th) & (bd.astype(np.float32) < np.float32(self.mfNNratio) * sd.astype(np.float32)), bi, -1).astype(np.int32)
+        if self.mbCheckOrientation:
+            aq = np.ascontiguousarray(kq["angle"], np.float32)
+            at = np.ascontiguousarray(kt["angle"], np.float32)
+            n = self.L.orbm_rot_filter(_p(aq), _p(at), _p(m), len(m))
+        else:
+            n = int((m >= 0).sum())
+        return n, m
+
+    def match_batch_device(self, d_q, d_kq, d_nq, d_t, d_kt, d_nt, cap, nbatch, d_match12, d_nmatches,
+                           th=None, stream=None):
+        th = self.TH_LOW if th is None else th
+        _mchk(self.L.orbm_match_batch_device(self.h, d_q, d_kq, d_nq, d_t, d_kt, d_nt, cap, nbatch, th,
+                                             self.mfNNratio, int(self.mbCheckOrientation), d_match12, d_nmatches, stream))

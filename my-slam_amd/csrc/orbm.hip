@@ -1,0 +1,445 @@
+// orbm.hip -- gfx950 Hamming matcher primitives + their C ABI (include/orbm.h).
+// Reference: src/ORBmatcher.cc of WChen09/My-SLAM (DescriptorDistance :1647-1663, best/second-best
+// loops :201-232 and siblings, ComputeThreeMaxima :1601-1642).  Integer/bitwise only: v_xor_b32 +
+// v_bcnt_u32_b32 (popcount with accumulate); the train set is staged through LDS in 8 KiB tiles and
+// read back as wave-uniform broadcasts, so the kernel is VALU-bound, not HBM-bound.
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include <hip/hip_runtime.h>
+#include "../../include/orbm.h"
+
+#define M_THREADS 256
+#define M_TILE 256
+
+static thread_local std::string g_merr;
+static int mfail(int code, const char *fmt, ...)
+{
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    g_merr = buf;
+    return code;
+}
+#define MHIPCHK(expr)                                                                            \
+    do {                                                                                         \
+        hipError_t e_ = (expr);                                                                  \
+        if (e_ != hipSuccess) return mfail(ORBX_E_HIP, "%s: %s", #expr, hipGetErrorString(e_)); \
+    } while (0)
+extern "C" const char *orbm_last_error(void) { return g_merr.c_str(); }
+
+__device__ __forceinline__ int hamming256(const uint4 &a0, const uint4 &a1, const uint4 &b0, const uint4 &b1)
+{
+    int d = __popc(a0.x ^ b0.x);
+    d += __popc(a0.y ^ b0.y);
+    d += __popc(a0.z ^ b0.z);
+    d += __popc(a0.w ^ b0.w);
+    d += __popc(a1.x ^ b1.x);
+    d += __popc(a1.y ^ b1.y);
+    d += __popc(a1.z ^ b1.z);
+    d += __popc(a1.w ^ b1.w);
+    return d;
+}
+
+// ---- dense best/second-best: one query per thread, train tiles broadcast from LDS ----
+__global__ __launch_bounds__(M_THREADS) void k_best2_dense(
+    const uint8_t *__restrict__ q, const int32_t *__restrict__ nqv, int nq_fixed,
+    const uint8_t *__restrict__ t, const int32_t *__restrict__ ntv, int nt_fixed,
+    long long qstride, long long tstride, int out_stride,
+    int32_t *__restrict__ best_idx, int32_t *__restrict__ best_d, int32_t *__restrict__ second_d)
+{
+    __shared__ uint4 tile[M_TILE * 2];
+    const int b = blockIdx.y, tid = threadIdx.x;
+    const int nq = nqv ? nqv[b] : nq_fixed;
+    const int nt = ntv ? ntv[b] : nt_fixed;
+    if ((int)(blockIdx.x * M_THREADS) >= nq) return;
+    const int qi = blockIdx.x * M_THREADS + tid;
+    const uint4 *Q = reinterpret_cast<const uint4 *>(q + (long long)b * qstride);
+    const uint4 *T = reinterpret_cast<const uint4 *>(t + (long long)b * tstride);
+    uint4 q0 = make_uint4(0, 0, 0, 0), q1 = q0;
+    if (qi < nq) { q0 = Q[2 * qi]; q1 = Q[2 * qi + 1]; }
+    int bd = 256, sd = 256, bi = -1;
+    for (int t0 = 0; t0 < nt; t0 += M_TILE) {
+        __syncthreads();
+        const int cnt = min(M_TILE, nt - t0);
+        for (int i = tid; i < cnt * 2; i += M_THREADS) tile[i] = T[2 * t0 + i];
+        __syncthreads();
+        if (qi < nq) {
+#pragma unroll 4
+            for (int j = 0; j < cnt; j++) {
+                const int d = hamming256(q0, q1, tile[2 * j], tile[2 * j + 1]);
+                if (d < bd) { sd = bd; bd = d; bi = t0 + j; }        // :214-219
+                else if (d < sd) { sd = d; }                        // :220-223
+            }
+        }
+    }
+    if (qi < nq) {
+        const long long o = (long long)b * out_stride + qi;
+        best_idx[o] = bi; best_d[o] = bd; second_d[o] = sd;
+    }
+}
+
+// ---- CSR best/second-best: one wave per query ----
+__global__ __launch_bounds__(M_THREADS) void k_best2_csr(
+    const uint8_t *__restrict__ q, int nq, const uint8_t *__restrict__ t,
+    const int32_t *__restrict__ off, const int32_t *__restrict__ idx,
+    int32_t *__restrict__ best_idx, int32_t *__restrict__ best_d, int32_t *__restrict__ second_d)
+{
+    const int lane = threadIdx.x & 63;
+    const int qi = blockIdx.x * (M_THREADS / 64) + (threadIdx.x >> 6);
+    if (qi >= nq) return;
+    const uint4 *Q = reinterpret_cast<const uint4 *>(q) + 2 * (long long)qi;
+    const uint4 q0 = Q[0], q1 = Q[1];
+    const int lo = off[qi], hi = off[qi + 1];
+    // pack = dist << 22 | position: min() picks the smallest distance, earliest position
+    uint32_t bp = (256u << 22) | 0x3FFFFFu;
+    int s = 256;
+    for (int c = lo + lane; c < hi; c += 64) {
+        const uint4 *Tj = reinterpret_cast<const uint4 *>(t) + 2 * (long long)idx[c];
+        const int d = hamming256(q0, q1, Tj[0], Tj[1]);
+        const uint32_t p = ((uint32_t)d << 22) | (uint32_t)min(c - lo, 0x3FFFFF);
+        if (p < bp) { s = (int)(bp >> 22); bp = p; }
+        else if (d < s) s = d;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const uint32_t op = __shfl_xor(bp, o);
+        const int os = __shfl_xor(s, o);
+        const int loser = (int)(max(bp, op) >> 22);
+        bp = min(bp, op);
+        s = min(min(s, os), loser);
+    }
+    if (lane == 0) {
+        const int d = (int)(bp >> 22);
+        best_d[qi] = d;
+        second_d[qi] = s;
+        best_idx[qi] = d < 256 ? idx[lo + (int)(bp & 0x3FFFFFu)] : -1;
+    }
+}
+
+// ---- per-candidate distances ----
+__global__ __launch_bounds__(M_THREADS) void k_dist_csr(
+    const uint8_t *__restrict__ q, int nq, const uint8_t *__restrict__ t,
+    const int32_t *__restrict__ off, const int32_t *__restrict__ idx, int total, int32_t *__restrict__ dist)
+{
+    const int c = blockIdx.x * M_THREADS + threadIdx.x;
+    if (c >= total) return;
+    int lo = 0, hi = nq;   // largest i with off[i] <= c
+    while (hi - lo > 1) {
+        const int mid = (lo + hi) >> 1;
+        if (off[mid] <= c) lo = mid; else hi = mid;
+    }
+    const uint4 *Q = reinterpret_cast<const uint4 *>(q) + 2 * (long long)lo;
+    const uint4 *Tj = reinterpret_cast<const uint4 *>(t) + 2 * (long long)idx[c];
+    dist[c] = hamming256(Q[0], Q[1], Tj[0], Tj[1]);
+}
+
+__global__ __launch_bounds__(M_THREADS) void k_dist_dense(
+    const uint8_t *__restrict__ q, int nq, const uint8_t *__restrict__ t, int nt, int32_t *__restrict__ dist)
+{
+    const long long c = (long long)blockIdx.x * M_THREADS + threadIdx.x;
+    if (c >= (long long)nq * nt) return;
+    const int i = (int)(c / nt), j = (int)(c - (long long)i * nt);
+    const uint4 *Q = reinterpret_cast<const uint4 *>(q) + 2 * (long long)i;
+    const uint4 *Tj = reinterpret_cast<const uint4 *>(t) + 2 * (long long)j;
+    dist[c] = hamming256(Q[0], Q[1], Tj[0], Tj[1]);
+}
+
+// ---- acceptance (:228-232) + rotation histogram (:236-246) + ComputeThreeMaxima + cull (:266-284) ----
+__device__ __forceinline__ int rot_bin(float a1, float a2)
+{
+    const float factor = 1.0f / 30;
+    float rot = __fsub_rn(a1, a2);
+    if (rot < 0.0f) rot = __fadd_rn(rot, 360.0f);
+    int bin = (int)roundf(__fmul_rn(rot, factor));
+    if (bin == 30) bin = 0;
+    return bin;
+}
+
+__device__ __forceinline__ void three_maxima(const int *histo, int L, int &ind1, int &ind2, int &ind3)
+{
+    int max1 = 0, max2 = 0, max3 = 0;
+    ind1 = ind2 = ind3 = -1;
+    for (int i = 0; i < L; i++) {
+        const int s = histo[i];
+        if (s > max1) { max3 = max2; max2 = max1; max1 = s; ind3 = ind2; ind2 = ind1; ind1 = i; }
+        else if (s > max2) { max3 = max2; max2 = s; ind3 = ind2; ind2 = i; }
+        else if (s > max3) { max3 = s; ind3 = i; }
+    }
+    if ((float)max2 < 0.1f * (float)max1) { ind2 = -1; ind3 = -1; }
+    else if ((float)max3 < 0.1f * (float)max1) { ind3 = -1; }
+}
+
+__global__ __launch_bounds__(M_THREADS) void k_accept_rot(
+    const int32_t *__restrict__ nqv, const orbx_keypoint *__restrict__ kq, const orbx_keypoint *__restrict__ kt,
+    int cap, const int32_t *__restrict__ best_idx, const int32_t *__restrict__ best_d,
+    const int32_t *__restrict__ second_d, int th, float nnratio, int check_ori,
+    int32_t *__restrict__ match12, int32_t *__restrict__ nmatches)
+{
+    __shared__ int hist[32];
+    __shared__ int s_ind[3];
+    __shared__ int s_count;
+    const int b = blockIdx.x, tid = threadIdx.x;
+    const int nq = nqv[b];
+    const long long base = (long long)b * cap;
+    if (tid < 32) hist[tid] = 0;
+    if (tid == 0) s_count = 0;
+    __syncthreads();
+    for (int i = tid; i < nq; i += M_THREADS) {
+        const int bd = best_d[base + i], sd = second_d[base + i];
+        int m = -1;
+        if (bd <= th && (float)bd < __fmul_rn(nnratio, (float)sd)) m = best_idx[base + i];
+        match12[base + i] = m;
+        if (m >= 0 && check_ori) atomicAdd(&hist[rot_bin(kq[base + i].angle, kt[base + m].angle)], 1);
+    }
+    __syncthreads();
+    if (tid == 0) {
+        int i1, i2, i3;
+        three_maxima(hist, 30, i1, i2, i3);
+        s_ind[0] = i1; s_ind[1] = i2; s_ind[2] = i3;
+    }
+    __syncthreads();
+    int cnt = 0;
+    for (int i = tid; i < nq; i += M_THREADS) {
+        int m = match12[base + i];
+        if (m >= 0 && check_ori) {
+            const int bin = rot_bin(kq[base + i].angle, kt[base + m].angle);
+            if (bin != s_ind[0] && bin != s_ind[1] && bin != s_ind[2]) { m = -1; match12[base + i] = -1; }
+        }
+        cnt += m >= 0;
+    }
+    for (int i = nq + tid; i < cap; i += M_THREADS) match12[base + i] = -1;
+    if (cnt) atomicAdd(&s_count, cnt);
+    __syncthreads();
+    if (tid == 0) nmatches[b] = s_count;
+}
+
+// -------------------------------------------------------------------------------------------------
+// C ABI
+// -------------------------------------------------------------------------------------------------
+struct orbm_matcher {
+    int device = 0, max_q = 0, max_t = 0, max_pairs = 0;
+    hipStream_t stream = nullptr;
+    uint8_t *d_q = nullptr, *d_t = nullptr;
+    int32_t *d_off = nullptr, *d_idx = nullptr, *d_out = nullptr;   // d_out: max(3*max_q, max_pairs) ints
+    int32_t *d_bi = nullptr, *d_bd = nullptr, *d_sd = nullptr;       // batch scratch (lazy)
+    size_t batch_elems = 0;
+};
+
+extern "C" int orbm_distance(const uint8_t a[32], const uint8_t b[32])
+{
+    int dist = 0;
+    for (int i = 0; i < 8; i++) {
+        uint32_t pa, pb;
+        memcpy(&pa, a + 4 * i, 4);
+        memcpy(&pb, b + 4 * i, 4);
+        dist += __builtin_popcount(pa ^ pb);
+    }
+    return dist;
+}
+
+extern "C" void orbm_destroy(orbm_matcher *m)
+{
+    if (!m) return;
+    (void)hipSetDevice(m->device);
+    (void)hipFree(m->d_q); (void)hipFree(m->d_t); (void)hipFree(m->d_off); (void)hipFree(m->d_idx);
+    (void)hipFree(m->d_out); (void)hipFree(m->d_bi); (void)hipFree(m->d_bd); (void)hipFree(m->d_sd);
+    if (m->stream) (void)hipStreamDestroy(m->stream);
+    delete m;
+}
+
+extern "C" int orbm_create(orbm_matcher **out, int device, int max_queries, int max_train, int max_pairs)
+{
+    if (!out) return mfail(ORBX_E_INVALID, "out is NULL");
+    *out = nullptr;
+    if (max_queries < 1 || max_train < 1 || max_pairs < 0) return mfail(ORBX_E_INVALID, "bad sizes");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return mfail(ORBX_E_HIP, "no HIP device: liborbx has no CPU path");
+    if (device < 0 || device >= ndev) return mfail(ORBX_E_INVALID, "device %d of %d", device, ndev);
+    MHIPCHK(hipSetDevice(device));
+    orbm_matcher *m = new orbm_matcher();
+    m->device = device; m->max_q = max_queries; m->max_t = max_train; m->max_pairs = max_pairs;
+    const size_t outn = std::max<size_t>((size_t)3 * max_queries, (size_t)max_pairs);
+    if (hipMalloc((void **)&m->d_q, (size_t)max_queries * 32) != hipSuccess ||
+        hipMalloc((void **)&m->d_t, (size_t)max_train * 32) != hipSuccess ||
+        hipMalloc((void **)&m->d_off, ((size_t)max_queries + 1) * 4) != hipSuccess ||
+        hipMalloc((void **)&m->d_idx, std::max<size_t>((size_t)max_pairs, 1) * 4) != hipSuccess ||
+        hipMalloc((void **)&m->d_out, outn * 4) != hipSuccess ||
+        hipStreamCreateWithFlags(&m->stream, hipStreamNonBlocking) != hipSuccess) {
+        orbm_destroy(m);
+        return mfail(ORBX_E_HIP, "matcher workspace allocation failed");
+    }
+    *out = m;
+    return ORBX_OK;
+}
+
+static int check_csr(const int32_t *off, const int32_t *idx, int nq, int nt, int max_pairs, int *total)
+{
+    if (off[0] != 0) return mfail(ORBX_E_INVALID, "cand_off[0] must be 0");
+    for (int i = 0; i < nq; i++)
+        if (off[i + 1] < off[i]) return mfail(ORBX_E_INVALID, "cand_off not monotone at %d", i);
+    *total = off[nq];
+    if (*total > max_pairs) return mfail(ORBX_E_CAPACITY, "%d candidate pairs, matcher sized for %d", *total, max_pairs);
+    if (*total > 0 && !idx) return mfail(ORBX_E_INVALID, "cand_idx is NULL");
+    for (int c = 0; c < *total; c++)
+        if (idx[c] < 0 || idx[c] >= nt) return mfail(ORBX_E_INVALID, "cand_idx[%d]=%d outside [0,%d)", c, idx[c], nt);
+    return ORBX_OK;
+}
+
+extern "C" int orbm_best2(orbm_matcher *m, const uint8_t *q, int nq, const uint8_t *t, int nt,
+                          const int32_t *cand_off, const int32_t *cand_idx,
+                          int32_t *best_idx, int32_t *best_d, int32_t *second_d)
+{
+    if (!m) return mfail(ORBX_E_INVALID, "NULL handle");
+    if (nq < 0 || nt < 0 || nq > m->max_q || nt > m->max_t) return mfail(ORBX_E_CAPACITY, "nq=%d nt=%d exceed matcher sizes %d/%d", nq, nt, m->max_q, m->max_t);
+    if (nq == 0) return ORBX_OK;
+    if (!q || !best_idx || !best_d || !second_d || (nt > 0 && !t)) return mfail(ORBX_E_INVALID, "NULL buffer");
+    MHIPCHK(hipSetDevice(m->device));
+    hipStream_t s = m->stream;
+    MHIPCHK(hipMemcpyAsync(m->d_q, q, (size_t)nq * 32, hipMemcpyHostToDevice, s));
+    if (nt > 0) MHIPCHK(hipMemcpyAsync(m->d_t, t, (size_t)nt * 32, hipMemcpyHostToDevice, s));
+    int32_t *o_bi = m->d_out, *o_bd = m->d_out + nq, *o_sd = m->d_out + 2 * (size_t)nq;
+    if (cand_off) {
+        int total = 0;
+        int rc = check_csr(cand_off, cand_idx, nq, nt, m->max_pairs, &total);
+        if (rc != ORBX_OK) return rc;
+        MHIPCHK(hipMemcpyAsync(m->d_off, cand_off, ((size_t)nq + 1) * 4, hipMemcpyHostToDevice, s));
+        if (total > 0) MHIPCHK(hipMemcpyAsync(m->d_idx, cand_idx, (size_t)total * 4, hipMemcpyHostToDevice, s));
+        hipLaunchKernelGGL(k_best2_csr, dim3((nq + 3) / 4), dim3(M_THREADS), 0, s, m->d_q, nq, m->d_t, m->d_off, m->d_idx, o_bi, o_bd, o_sd);
+    } else {
+        hipLaunchKernelGGL(k_best2_dense, dim3((nq + M_THREADS - 1) / M_THREADS, 1), dim3(M_THREADS), 0, s,
+                           m->d_q, (const int32_t *)nullptr, nq, m->d_t, (const int32_t *)nullptr, nt, 0LL, 0LL, 0, o_bi, o_bd, o_sd);
+    }
+    MHIPCHK(hipGetLastError());
+    MHIPCHK(hipMemcpyAsync(best_idx, o_bi, (size_t)nq * 4, hipMemcpyDeviceToHost, s));
+    MHIPCHK(hipMemcpyAsync(best_d, o_bd, (size_t)nq * 4, hipMemcpyDeviceToHost, s));
+    MHIPCHK(hipMemcpyAsync(second_d, o_sd, (size_t)nq * 4, hipMemcpyDeviceToHost, s));
+    MHIPCHK(hipStreamSynchronize(s));
+    return ORBX_OK;
+}
+
+extern "C" int orbm_distances(orbm_matcher *m, const uint8_t *q, int nq, const uint8_t *t, int nt,
+                              const int32_t *cand_off, const int32_t *cand_idx, int32_t *dist)
+{
+    if (!m) return mfail(ORBX_E_INVALID, "NULL handle");
+    if (nq < 0 || nt < 0 || nq > m->max_q || nt > m->max_t) return mfail(ORBX_E_CAPACITY, "nq=%d nt=%d exceed matcher sizes", nq, nt);
+    if (nq == 0 || nt == 0) return ORBX_OK;
+    if (!q || !t || !dist) return mfail(ORBX_E_INVALID, "NULL buffer");
+    MHIPCHK(hipSetDevice(m->device));
+    hipStream_t s = m->stream;
+    MHIPCHK(hipMemcpyAsync(m->d_q, q, (size_t)nq * 32, hipMemcpyHostToDevice, s));
+    MHIPCHK(hipMemcpyAsync(m->d_t, t, (size_t)nt * 32, hipMemcpyHostToDevice, s));
+    long long total;
+    if (cand_off) {
+        int tot = 0;
+        int rc = check_csr(cand_off, cand_idx, nq, nt, m->max_pairs, &tot);
+        if (rc != ORBX_OK) return rc;
+        total = tot;
+        if (total == 0) return ORBX_OK;
+        MHIPCHK(hipMemcpyAsync(m->d_off, cand_off, ((size_t)nq + 1) * 4, hipMemcpyHostToDevice, s));
+        MHIPCHK(hipMemcpyAsync(m->d_idx, cand_idx, (size_t)total * 4, hipMemcpyHostToDevice, s));
+        hipLaunchKernelGGL(k_dist_csr, dim3((unsigned)((total + M_THREADS - 1) / M_THREADS)), dim3(M_THREADS), 0, s,
+                           m->d_q, nq, m->d_t, m->d_off, m->d_idx, (int)total, m->d_out);
+    } else {
+        total = (long long)nq * nt;
+        if (total > (long long)std::max<size_t>((size_t)3 * m->max_q, (size_t)m->max_pairs))
+            return mfail(ORBX_E_CAPACITY, "dense distances need %lld ints, matcher sized for %d pairs", total, m->max_pairs);
+        hipLaunchKernelGGL(k_dist_dense, dim3((unsigned)((total + M_THREADS - 1) / M_THREADS)), dim3(M_THREADS), 0, s,
+                           m->d_q, nq, m->d_t, nt, m->d_out);
+    }
+    MHIPCHK(hipGetLastError());
+    MHIPCHK(hipMemcpyAsync(dist, m->d_out, (size_t)total * 4, hipMemcpyDeviceToHost, s));
+    MHIPCHK(hipStreamSynchronize(s));
+    return ORBX_OK;
+}
+
+extern "C" int orbm_best2_batch_device(orbm_matcher *m, const uint8_t *d_q, const int32_t *d_nq,
+                                       const uint8_t *d_t, const int32_t *d_nt, int cap, int nbatch,
+                                       int32_t *d_best_idx, int32_t *d_best_d, int32_t *d_second_d, void *hip_stream)
+{
+    if (!m) return mfail(ORBX_E_INVALID, "NULL handle");
+    if (!d_q || !d_nq || !d_t || !d_nt || !d_best_idx || !d_best_d || !d_second_d) return mfail(ORBX_E_INVALID, "NULL device pointer");
+    if (cap < 1 || nbatch < 1) return mfail(ORBX_E_INVALID, "cap=%d nbatch=%d", cap, nbatch);
+    MHIPCHK(hipSetDevice(m->device));
+    hipStream_t s = hip_stream ? (hipStream_t)hip_stream : m->stream;
+    hipLaunchKernelGGL(k_best2_dense, dim3((cap + M_THREADS - 1) / M_THREADS, nbatch), dim3(M_THREADS), 0, s,
+                       d_q, d_nq, 0, d_t, d_nt, 0, (long long)cap * 32, (long long)cap * 32, cap,
+                       d_best_idx, d_best_d, d_second_d);
+    MHIPCHK(hipGetLastError());
+    return ORBX_OK;
+}
+
+extern "C" int orbm_match_batch_device(orbm_matcher *m, const uint8_t *d_q, const orbx_keypoint *d_kq,
+                                       const int32_t *d_nq, const uint8_t *d_t, const orbx_keypoint *d_kt,
+                                       const int32_t *d_nt, int cap, int nbatch, int th, float nnratio,
+                                       int check_orientation, int32_t *d_match12, int32_t *d_nmatches, void *hip_stream)
+{
+    if (!m) return mfail(ORBX_E_INVALID, "NULL handle");
+    if (!d_kq || !d_kt || !d_match12 || !d_nmatches) return mfail(ORBX_E_INVALID, "NULL device pointer");
+    MHIPCHK(hipSetDevice(m->device));
+    const size_t need = (size_t)cap * nbatch;
+    if (need > m->batch_elems) {
+        MHIPCHK(hipDeviceSynchronize());
+        (void)hipFree(m->d_bi); (void)hipFree(m->d_bd); (void)hipFree(m->d_sd);
+        m->d_bi = m->d_bd = m->d_sd = nullptr; m->batch_elems = 0;
+        MHIPCHK(hipMalloc((void **)&m->d_bi, need * 4));
+        MHIPCHK(hipMalloc((void **)&m->d_bd, need * 4));
+        MHIPCHK(hipMalloc((void **)&m->d_sd, need * 4));
+        m->batch_elems = need;
+    }
+    int rc = orbm_best2_batch_device(m, d_q, d_nq, d_t, d_nt, cap, nbatch, m->d_bi, m->d_bd, m->d_sd, hip_stream);
+    if (rc != ORBX_OK) return rc;
+    hipStream_t s = hip_stream ? (hipStream_t)hip_stream : m->stream;
+    hipLaunchKernelGGL(k_accept_rot, dim3(nbatch), dim3(M_THREADS), 0, s, d_nq, d_kq, d_kt, cap, m->d_bi, m->d_bd, m->d_sd,
+                       th, nnratio, check_orientation, d_match12, d_nmatches);
+    MHIPCHK(hipGetLastError());
+    return ORBX_OK;
+}
+
+// ---- host helpers (ComputeThreeMaxima :1601-1642, histogram fill/cull :236-246,:266-284) ----
+extern "C" int orbm_three_maxima(const int32_t *histo, int L, int32_t ind[3])
+{
+    if (!histo || !ind || L < 0) return mfail(ORBX_E_INVALID, "bad argument");
+    int max1 = 0, max2 = 0, max3 = 0, ind1 = -1, ind2 = -1, ind3 = -1;
+    for (int i = 0; i < L; i++) {
+        const int s = histo[i];
+        if (s > max1) { max3 = max2; max2 = max1; max1 = s; ind3 = ind2; ind2 = ind1; ind1 = i; }
+        else if (s > max2) { max3 = max2; max2 = s; ind3 = ind2; ind2 = i; }
+        else if (s > max3) { max3 = s; ind3 = i; }
+    }
+    if (max2 < 0.1f * (float)max1) { ind2 = -1; ind3 = -1; }
+    else if (max3 < 0.1f * (float)max1) { ind3 = -1; }
+    ind[0] = ind1; ind[1] = ind2; ind[2] = ind3;
+    return ORBX_OK;
+}
+
+extern "C" int orbm_rot_filter(const float *angle_q, const float *angle_t, int32_t *match12, int nq)
+{
+    if (nq < 0 || (nq > 0 && (!angle_q || !angle_t || !match12))) return mfail(ORBX_E_INVALID, "bad argument");
+    int32_t hist[ORBM_HISTO_LENGTH] = {0};
+    std::vector<int> bins(nq, -1);
+    int nmatches = 0;
+    const float factor = 1.0f / ORBM_HISTO_LENGTH;
+    for (int i = 0; i < nq; i++) {
+        if (match12[i] < 0) continue;
+        float rot = angle_q[i] - angle_t[match12[i]];
+        if (rot < 0.0) rot += 360.0f;
+        int bin = (int)roundf(rot * factor);
+        if (bin == ORBM_HISTO_LENGTH) bin = 0;
+        bins[i] = bin;
+        hist[bin]++;
+        nmatches++;
+    }
+    int32_t ind[3];
+    orbm_three_maxima(hist, ORBM_HISTO_LENGTH, ind);
+    for (int i = 0; i < nq; i++)
+        if (bins[i] >= 0 && bins[i] != ind[0] && bins[i] != ind[1] && bins[i] != ind[2]) { match12[i] = -1; nmatches--; }
+    return nmatches;
+}

@@ -1,0 +1,76 @@
+"""GPU parity for the Hamming primitives: HIP (through the C ABI) == oracle, exactly."""
+import numpy as np
+import pytest
+
+import oracle_lib as O
+
+pytestmark = pytest.mark.gpu
+
+
+def _rand_desc(rng, n, clusters=None):
+    d = rng.integers(0, 256, size=(n, 32), dtype=np.uint8)
+    if clusters is not None:   # near-duplicates so that ties and small distances occur
+        base = rng.integers(0, 256, size=(clusters, 32), dtype=np.uint8)
+        d = base[rng.integers(0, clusters, n)].copy()
+        flips = rng.integers(0, 256, size=(n, 3))
+        for i in range(n):
+            for b in flips[i]:
+                d[i, b >> 3] ^= np.uint8(1 << (b & 7))
+    return d
+
+
+@pytest.mark.parametrize("nq,nt", [(1, 1), (7, 300), (1000, 1003), (4000, 4001)])
+def test_best2_dense(orbx, nq, nt):
+    rng = np.random.default_rng(nq * 7 + nt)
+    q, t = _rand_desc(rng, nq, 40), _rand_desc(rng, nt, 40)
+    m = orbx.ORBmatcher()
+    bi, bd, sd = m.best2(q, t)
+    obi, obd, osd = O.best2(q, t)
+    assert np.array_equal(bd, obd) and np.array_equal(sd, osd) and np.array_equal(bi, obi)
+
+
+def test_best2_csr_and_distances(orbx):
+    rng = np.random.default_rng(5)
+    nq, nt = 777, 900
+    q, t = _rand_desc(rng, nq, 30), _rand_desc(rng, nt, 30)
+    lens = rng.integers(0, 150, nq)
+    lens[::50] = 0                       # empty candidate lists
+    off = np.zeros(nq + 1, np.int32)
+    off[1:] = np.cumsum(lens)
+    idx = rng.integers(0, nt, int(off[-1])).astype(np.int32)
+    m = orbx.ORBmatcher()
+    bi, bd, sd = m.best2(q, t, off, idx)
+    obi, obd, osd = O.best2(q, t, off, idx)
+    assert np.array_equal(bd, obd) and np.array_equal(sd, osd) and np.array_equal(bi, obi)
+    d = m.distances(q, t, off, idx)
+    L = O.lib()
+    ref = np.array([L.oro_descriptor_distance(q[i].ctypes.data, t[idx[c]].ctypes.data)
+                    for i in range(nq) for c in range(off[i], off[i + 1])], np.int32)
+    assert np.array_equal(d, ref)
+    dd = m.distances(q[:50], t[:60])
+    ref = np.array([[L.oro_descriptor_distance(q[i].ctypes.data, t[j].ctypes.data) for j in range(60)] for i in range(50)], np.int32)
+    assert np.array_equal(dd.reshape(50, 60), ref)
+
+
+def test_descriptor_distance_host(orbx):
+    rng = np.random.default_rng(1)
+    a, b = _rand_desc(rng, 64), _rand_desc(rng, 64)
+    L = O.lib()
+    for i in range(64):
+        assert orbx.ORBmatcher.DescriptorDistance(a[i], b[i]) == L.oro_descriptor_distance(a[i].ctypes.data, b[i].ctypes.data)
+    assert orbx.ORBmatcher.DescriptorDistance(a[0], a[0]) == 0
+    assert orbx.ORBmatcher.DescriptorDistance(np.zeros(32, np.uint8), np.full(32, 255, np.uint8)) == 256
+
+
+def test_extract_then_match_frame_pair(orbx, synth):
+    """BASELINE config 3 shape (reduced): extract two shifted frames, dense match with rotation filter."""
+    W, H, n = 960, 540, 2000
+    f0, f1 = synth.frame_pair(2, W, H)
+    ex = orbx.ORBextractor(n, max_width=W, max_height=H)
+    k0, d0 = ex(f0)
+    k1, d1 = ex(f1)
+    m = orbx.ORBmatcher(0.9, True)
+    nm, m12 = m.match_dense(d1, k1, d0, k0)
+    onm, om12 = O.match_dense(d1, k1["angle"], d0, k0["angle"], 50, 0.9, True)
+    assert nm == onm and np.array_equal(m12, om12)
+    assert nm > 300     # the shifted frame really matches
