@@ -133,8 +133,14 @@ def main():
         gather_bufs = ([torch.empty_like(kps) for _ in range(world)], [torch.empty_like(desc) for _ in range(world)],
                        [torch.empty_like(counts) for _ in range(world)])
 
+    # one explicit (non-default) stream carries the whole path, so extract -> match -> gather are
+    # ordered by the stream itself (a NULL stream would select each handle's private stream)
+    stream = torch.cuda.Stream()
+    torch.cuda.set_stream(stream)
+    s = stream.cuda_stream
+    assert s != 0
+
     def step():
-        s = torch.cuda.current_stream().cuda_stream
         ex.extract_batch_device(frames.data_ptr(), B, W, H, frames.stride(1), frames.stride(0),
                                 kps.data_ptr(), desc.data_ptr(), counts.data_ptr(), status.data_ptr(), s)
         if do_match:   # frame k (query) against frame k-1 (train), k = 1..B-1
@@ -182,7 +188,6 @@ def main():
         tm = 0.0
         reps = max(3, min(10, args.steps))
         for _ in range(reps):
-            s = torch.cuda.current_stream().cuda_stream
             ex.extract_batch_device(frames.data_ptr(), B, W, H, frames.stride(1), frames.stride(0),
                                     kps.data_ptr(), desc.data_ptr(), counts.data_ptr(), status.data_ptr(), s)
             acc += ex.stage_ms()

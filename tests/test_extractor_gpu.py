@@ -53,3 +53,145 @@ def test_batch_equals_single(orbx, synth):
     for k in range(4):
         okps, odesc, _ = oex.extract(frames[k])
         _compare(res[k][0], res[k][1], okps, odesc, "frame %d" % k)
+
+
+# ---- committed fixtures: no oracle build needed for these ----
+import glob
+import os
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+GCASES = sorted(p for p in glob.glob(os.path.join(GOLDEN, "*.npz")) if not os.path.basename(p).startswith("match"))
+
+
+@pytest.mark.parametrize("path", GCASES, ids=[os.path.basename(p)[:-4] for p in GCASES])
+def test_hip_reproduces_golden(orbx, synth, path):
+    g = np.load(path)
+    W, H = int(g["W"]), int(g["H"])
+    img = synth.texture(int(g["seed"]), W, H)
+    ex = orbx.ORBextractor(int(g["nfeatures"]), max_width=W, max_height=H)
+    ex.set_blur_rounding(int(g["blur_mode"]))
+    kps, desc = ex(img)
+    assert kps.tobytes() == g["keypoints"].tobytes()
+    assert np.array_equal(desc, g["descriptors"])
+
+
+def test_config3_1080p_n4000(orbx, synth):
+    """BASELINE configs[2]: 1920x1080, nFeatures=4000, extract both frames + dense match vs previous."""
+    f0, f1 = synth.frame_pair(2, 1920, 1080)
+    ex = orbx.ORBextractor(4000, max_width=1920, max_height=1080)
+    oex = O.Extractor(4000)
+    k0, d0 = ex(f0)
+    ok0, od0, _ = oex.extract(f0)
+    _compare(k0, d0, ok0, od0, "1080p f0")
+    k1, d1 = ex(f1)
+    ok1, od1, _ = oex.extract(f1)
+    _compare(k1, d1, ok1, od1, "1080p f1")
+    m = orbx.ORBmatcher(0.9, True)
+    nm, m12 = m.match_dense(d1, k1, d0, k0)
+    onm, om12 = O.match_dense(od1, ok1["angle"], od0, ok0["angle"], 50, 0.9, True)
+    assert nm == onm and np.array_equal(m12, om12) and nm > 1000
+
+
+def test_config4_batch64_stream(orbx, synth):
+    """BASELINE configs[3] on one GPU: 64 x 640x480 stream in one call; every frame == oracle on a
+    sample, and the call is idempotent (size-independent property for the rest)."""
+    frames = synth.stream(4, 640, 480, 64)
+    ex = orbx.ORBextractor(1000, max_width=640, max_height=480, max_batch=64)
+    r1 = ex.extract_batch(frames)
+    r2 = ex.extract_batch(frames)
+    oex = O.Extractor(1000)
+    for k in range(64):
+        assert r1[k][0].tobytes() == r2[k][0].tobytes() and np.array_equal(r1[k][1], r2[k][1])
+        assert 900 <= len(r1[k][0]) <= ex.cap
+    for k in (0, 17, 63):
+        okps, odesc, _ = oex.extract(frames[k])
+        _compare(r1[k][0], r1[k][1], okps, odesc, "frame %d" % k)
+
+
+@pytest.mark.parametrize("params", [
+    dict(nfeatures=50, scaleFactor=1.2, nlevels=8, iniThFAST=20, minThFAST=7),
+    dict(nfeatures=700, scaleFactor=1.5, nlevels=4, iniThFAST=30, minThFAST=10),
+    dict(nfeatures=300, scaleFactor=2.0, nlevels=3, iniThFAST=20, minThFAST=7),      # exact 2x: INTER_AREA path
+    dict(nfeatures=2000, scaleFactor=1.2, nlevels=8, iniThFAST=7, minThFAST=7),
+    dict(nfeatures=500, scaleFactor=1.1, nlevels=12, iniThFAST=12, minThFAST=20),   # ini < min
+    dict(nfeatures=1, scaleFactor=1.2, nlevels=8, iniThFAST=20, minThFAST=7),       # quotas of 0
+])
+def test_parameter_sweep(orbx, synth, params):
+    W, H = 512, 384
+    img = synth.texture(21, W, H)
+    ex = orbx.ORBextractor(max_width=W, max_height=H, **params)
+    kps, desc = ex(img)
+    okps, odesc, _ = O.Extractor(params["nfeatures"], params["scaleFactor"], params["nlevels"],
+                                 params["iniThFAST"], params["minThFAST"]).extract(img)
+    _compare(kps, desc, okps, odesc, str(params))
+    assert np.array_equal(ex.GetScaleFactors(), np.array(list(O.Extractor(1, params["scaleFactor"], params["nlevels"]).e.scale)[:params["nlevels"]], np.float32))
+
+
+def test_edge_inputs(orbx, synth):
+    ex = orbx.ORBextractor(500, max_width=640, max_height=480)
+    # empty image: the reference returns silently (src/ORBextractor.cc:1048)
+    k, d = ex(np.zeros((0, 0), np.uint8))
+    assert len(k) == 0 and d.shape == (0, 32)
+    # flat image: no corner anywhere
+    k, d = ex(np.full((480, 640), 93, np.uint8))
+    assert len(k) == 0
+    # row stride > width (a cv::Mat ROI)
+    big = synth.texture(5, 700, 480)
+    roi = big[:, 30:670]
+    assert roi.strides[0] == 700
+    k, d = ex(roi)
+    ok, od, _ = O.Extractor(500).extract(np.ascontiguousarray(roi))
+    _compare(k, d, ok, od, "roi")
+    # a different (smaller) shape on the same handle re-plans; tiny levels have no cells
+    small = synth.texture(6, 150, 120)
+    k, d = ex(small)
+    ok, od, _ = O.Extractor(500).extract(small)
+    _compare(k, d, ok, od, "small")
+    # and back
+    k, d = ex(np.ascontiguousarray(roi))
+    _compare(k, d, ok if False else O.Extractor(500).extract(np.ascontiguousarray(roi))[0], od if False else O.Extractor(500).extract(np.ascontiguousarray(roi))[1], "back")
+    # larger than the handle's maximum / portrait shapes the reference cannot process
+    with pytest.raises(orbx.OrbxError) as ei:
+        ex(np.zeros((481, 640), np.uint8))
+    assert ei.value.code == orbx.ORBX_E_SHAPE
+    with pytest.raises(orbx.OrbxError) as ei:
+        orbx.ORBextractor(500, max_width=200, max_height=480)
+    assert ei.value.code == orbx.ORBX_E_SHAPE
+    # caller capacity too small
+    kp = np.zeros(10, orbx.KP_DTYPE); de = np.zeros((10, 32), np.uint8)
+    import ctypes as C
+    n = C.c_int()
+    img = synth.texture(5, 640, 480)
+    rc = ex.L.orbx_extract(ex.h, img.ctypes.data, 640, 480, 640, kp.ctypes.data, de.ctypes.data, 10, C.byref(n))
+    assert rc == orbx.ORBX_E_CAPACITY
+
+
+def test_saturated_and_noisy_images(orbx):
+    """Extreme inputs: white frame with dark dots (blur saturation at 255), and uniform noise (the
+    densest candidate field; must either match the oracle or report candidate overflow)."""
+    rng = np.random.default_rng(3)
+    img = np.full((240, 320), 255, np.uint8)
+    ys, xs = rng.integers(25, 215, 300), rng.integers(25, 295, 300)
+    img[ys, xs] = 0
+    ex = orbx.ORBextractor(500, max_width=320, max_height=240)
+    k, d = ex(img)
+    ok, od, _ = O.Extractor(500).extract(img)
+    _compare(k, d, ok, od, "dots")
+    noise = rng.integers(0, 256, (240, 320), dtype=np.uint8)
+    try:
+        k, d = ex(noise)
+    except orbx.OrbxError as e:
+        assert e.code == orbx.ORBX_E_CAND_OVERFLOW
+    else:
+        ok, od, _ = O.Extractor(500).extract(noise)
+        _compare(k, d, ok, od, "noise")
+
+
+def test_pyramid_border_download(orbx, synth):
+    img = synth.texture(8, 320, 240)
+    ex = orbx.ORBextractor(300, max_width=320, max_height=240)
+    ex(img)
+    pyr = ex.image_pyramid(border=19)
+    opyr = O.Extractor(300).pyramid(img)
+    for l in range(8):
+        assert np.array_equal(pyr[l], np.pad(opyr[l], 19, mode="reflect"))     # copyMakeBorder REFLECT_101
