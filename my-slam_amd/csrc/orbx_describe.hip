@@ -5,13 +5,18 @@
 #include "orbx_internal.h"
 #include "orb_pattern_data.h"
 
-__constant__ int c_umax[16];
+__constant__ unsigned long long c_umax_nib;   // umax[v] in nibble v (v = 0..15)
 __constant__ int c_gauss[7];
 __constant__ signed char c_pattern[1024];
 
 int orbx_upload_constants(const int umax[16], const int gauss_k[7])
 {
-    if (hipMemcpyToSymbol(HIP_SYMBOL(c_umax), umax, sizeof(int) * 16) != hipSuccess) return -1;
+    unsigned long long nib = 0;
+    for (int v = 0; v < 16; v++) {
+        if (umax[v] < 0 || umax[v] > 15) return -1;
+        nib |= (unsigned long long)umax[v] << (4 * v);
+    }
+    if (hipMemcpyToSymbol(HIP_SYMBOL(c_umax_nib), &nib, sizeof(nib)) != hipSuccess) return -1;
     if (hipMemcpyToSymbol(HIP_SYMBOL(c_gauss), gauss_k, sizeof(int) * 7) != hipSuccess) return -1;
     if (hipMemcpyToSymbol(HIP_SYMBOL(c_pattern), ORBX_PATTERN, 1024) != hipSuccess) return -1;
     return 0;
@@ -116,14 +121,40 @@ extern "C" int orbx_debug_sincos(const float *h_theta, float *h_cos, float *h_si
     return e == hipSuccess ? ORBX_OK : ORBX_E_HIP;
 }
 
-__global__ __launch_bounds__(DESC_THREADS) void k_describe(
+// One wave per keypoint, four independent waves per workgroup (no workgroup barrier).  LDS per wave:
+//   raw  44 x 48 B   the 43x43 tile around the keypoint, column 0 at byte 0 (re-aligned at load time)
+//   P    22 x 160 B  row-blurred values, two vertically adjacent rows packed per dword (u16 | u16 << 16)
+//   bl   37 x 40 B   blurred 37x37 (aliases raw, which is dead by then)
+// Row pass: 4 outputs from 3 dword reads with v_alignbyte_b32 windows and v_dot4_u32_u8 (taps are u8).
+// Column pass: the vertical pairs make every output 4 x v_dot2_u32_u16; exact integer sums, one
+// rounding at the end -- identical to row-then-column on u8 -> int32 -> u8 (OpenCV's fixed-point path).
+#define DW_RAW_STRIDE 48
+#define DW_RAW_ROWS 44
+#define DW_P_STRIDE 40      // dwords per row pair
+#define DW_P_ROWS 22
+#define DW_BL_STRIDE 40
+
+struct __attribute__((aligned(16))) DescLds {
+    uint8_t raw[DW_RAW_STRIDE * DW_RAW_ROWS];   // 2112 B (bl aliases this)
+    uint32_t P[DW_P_STRIDE * DW_P_ROWS];        // 3520 B
+};
+
+#define DSYNC()                                                \
+    do {                                                       \
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); \
+        __builtin_amdgcn_wave_barrier();                       \
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); \
+    } while (0)
+
+__global__ __launch_bounds__(256) void k_describe(
     OrbxPlan plan, OrbxWork wk, orbx_keypoint *__restrict__ kps, uint8_t *__restrict__ desc,
-    int32_t *__restrict__ counts, int32_t *__restrict__ status)
+    int32_t *__restrict__ counts, int32_t *__restrict__ status, int l0_aligned)
 {
-    __shared__ uint8_t raw[DESC_RAW * 44];
-    __shared__ uint16_t rb[DESC_RAW * 38];
-    __shared__ uint8_t bl[DESC_BL * 40];
-    const int g = blockIdx.x, f = blockIdx.y, lane = threadIdx.x;
+    __shared__ DescLds lds[4];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int g = blockIdx.x * 4 + wave, f = blockIdx.y;
+    DescLds &S = lds[wave];
 
     int total = 0, l = -1, idx = 0;
     for (int i = 0; i < plan.nlevels; i++) {
@@ -141,75 +172,177 @@ __global__ __launch_bounds__(DESC_THREADS) void k_describe(
     if (l < 0 || g >= plan.out_cap) return;
     const OrbxLevel &L = plan.lv[l];
     const OrbxCand kc = wk.sel[(long long)f * plan.list_frame + L.list_off + idx];
-    const int x = (int)(kc.xy & 0xFFFFu), y = (int)(kc.xy >> 16);
+    const int x = __builtin_amdgcn_readfirstlane((int)(kc.xy & 0xFFFFu));
+    const int y = __builtin_amdgcn_readfirstlane((int)(kc.xy >> 16));
     const uint8_t *img = L.base + (long long)f * L.frame_stride;
 
-    for (int i = lane; i < DESC_RAW * DESC_RAW; i += DESC_THREADS) {
-        const int r = i / DESC_RAW, c = i - r * DESC_RAW;
-        const int gy = reflect101(y - 21 + r, L.h), gx = reflect101(x - 21 + c, L.w);
-        raw[r * 44 + c] = img[(long long)gy * L.stride + gx];
-    }
-    __syncthreads();
+    // this lane's four sample pairs (bits lane, lane+64, lane+128, lane+192); issued early
+    const uint32_t *pat32 = reinterpret_cast<const uint32_t *>(c_pattern);
+    const uint32_t pw0 = pat32[lane], pw1 = pat32[64 + lane], pw2 = pat32[128 + lane], pw3 = pat32[192 + lane];
 
-    // IC_Angle (:79-106): m10 = sum u*I, m01 = sum v*I over |u| <= umax[|v|]
-    int m10 = 0, m01 = 0;
-    for (int i = lane; i < 31 * 31; i += DESC_THREADS) {
-        const int vr = i / 31, v = vr - 15, u = i - vr * 31 - 15;
-        if (abs(u) <= c_umax[abs(v)]) {
-            const int I = raw[(21 + v) * 44 + 21 + u];
-            m10 += u * I;
-            m01 += v * I;
+    // ---- raw tile -> LDS ----
+    const int x0 = x - 21, y0 = y - 21;
+    const int row_bytes = (l == 0) ? L.w : L.stride;   // bytes of a row that may be touched
+    const bool fast = (x0 >= 0) && (y0 >= 0) && (y + 21 < L.h) && (x + 21 < L.w) &&   // no reflection needed
+                      (x + 27 < row_bytes) &&                                          // dword over-read stays in the row
+                      (l != 0 || l0_aligned);
+    if (fast) {
+        const int xo = x0 & 3;
+        const int rr = lane / 12, d = lane - rr * 12;     // 5 rows per pass, 12 dwords per row
+        const uint8_t *src = img + (long long)(y0 + rr) * L.stride + (x0 & ~3) + 4 * d;
+        uint32_t gv[9];
+#pragma unroll
+        for (int p = 0; p < 9; p++) {
+            const int r = p * 5 + rr;
+            gv[p] = (lane < 60 && r < 43) ? *reinterpret_cast<const uint32_t *>(src + (long long)(p * 5) * L.stride) : 0u;
+        }
+#pragma unroll
+        for (int p = 0; p < 9; p++) {
+            const uint32_t hi = __shfl_down(gv[p], 1);
+            const uint32_t v = xo == 0 ? gv[p] : xo == 1 ? __builtin_amdgcn_alignbyte(hi, gv[p], 1)
+                             : xo == 2 ? __builtin_amdgcn_alignbyte(hi, gv[p], 2) : __builtin_amdgcn_alignbyte(hi, gv[p], 3);
+            const int r = p * 5 + rr;
+            if (lane < 60 && r < 43 && d < 11) *reinterpret_cast<uint32_t *>(&S.raw[r * DW_RAW_STRIDE + 4 * d]) = v;
+        }
+    } else {   // tile crosses the image border (reflect-101) or unaligned level 0: byte path
+        for (int i = lane; i < DESC_RAW * DESC_RAW; i += 64) {
+            const int r = i / DESC_RAW, c = i - r * DESC_RAW;
+            const int gy = reflect101(y0 + r, L.h), gx = reflect101(x0 + c, L.w);
+            S.raw[r * DW_RAW_STRIDE + c] = img[(long long)gy * L.stride + gx];
         }
     }
+    DSYNC();
+
+    // ---- IC_Angle (:79-106): m10 = sum u*I, m01 = sum v*I over |u| <= umax[|v|] ----
+    // dword tasks (row 0..30, dword 1..9 of the raw row); weights (u+32) keep the dot product unsigned
+    int m10 = 0, m01 = 0;
+    {
+        const unsigned long long unib = c_umax_nib;
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-        m10 += __shfl_xor(m10, o);
-        m01 += __shfl_xor(m01, o);
+        for (int it = 0; it < 5; it++) {
+            const int t = it * 64 + lane;
+            if (t < 31 * 9) {
+                const int vr = t / 9, dw = t - vr * 9 + 1;
+                const int v = vr - 15;
+                const int um = (int)((unib >> (4 * abs(v))) & 15ull);
+                const int lo = 21 - um, hi = 21 + um;               // valid raw columns
+                const int c0 = 4 * dw;
+                const int nlo = min(max(lo - c0, 0), 4), nhi = min(max(c0 + 3 - hi, 0), 4);
+                const uint32_t mlo = nlo >= 4 ? 0u : (0xFFFFFFFFu << (8 * nlo));
+                const uint32_t mhi = nhi >= 4 ? 0u : (0xFFFFFFFFu >> (8 * nhi));
+                const uint32_t msk = mlo & mhi;
+                // byte j holds u + 32 = (c0 + j - 21) + 32 = c0 + j + 11  (15..50: no carry between bytes)
+                const uint32_t wfull = (uint32_t)(c0 + 11) * 0x01010101u + 0x03020100u;
+                const uint32_t pix = *reinterpret_cast<const uint32_t *>(&S.raw[(6 + vr) * DW_RAW_STRIDE + c0]);
+                const int sA = (int)__builtin_amdgcn_udot4(pix, wfull & msk, 0u, false);
+                const int sB = (int)__builtin_amdgcn_udot4(pix, 0x01010101u & msk, 0u, false);
+                m10 += sA - 32 * sB;
+                m01 += v * sB;
+            }
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            m10 += __shfl_xor(m10, o);
+            m01 += __shfl_xor(m01, o);
+        }
     }
     const float angle = fast_atan2_deg((float)m01, (float)m10);
 
-    // 7x7 Gaussian, row pass (exact, <= 65535)
-    const int k0 = c_gauss[0], k1 = c_gauss[1], k2 = c_gauss[2], k3 = c_gauss[3];
-    for (int i = lane; i < DESC_RAW * DESC_BL; i += DESC_THREADS) {
-        const int r = i / DESC_BL, c = i - r * DESC_BL;
-        const uint8_t *p = &raw[r * 44 + c];
-        rb[r * 38 + c] = (uint16_t)(k0 * (p[0] + p[6]) + k1 * (p[1] + p[5]) + k2 * (p[2] + p[4]) + k3 * p[3]);
-    }
-    __syncthreads();
-    // column pass: (sum + 32768) >> 16 saturated (OpenCV C path) or round-half-even (OpenCV SSE2 path)
-    const int simd_cols = plan.blur_mode == 1 ? (L.w & ~3) : 0;
-    for (int i = lane; i < DESC_BL * DESC_BL; i += DESC_THREADS) {
-        const int r = i / DESC_BL, c = i - r * DESC_BL;
-        const uint16_t *p = &rb[r * 38 + c];
-        const int s = k0 * (p[0] + p[6 * 38]) + k1 * (p[38] + p[5 * 38]) + k2 * (p[2 * 38] + p[4 * 38]) + k3 * p[3 * 38];
-        int v;
-        if (x - DESC_R + c < simd_cols) {
-            v = s >> 16;
-            const int rem = s & 0xFFFF;
-            if (rem > 0x8000 || (rem == 0x8000 && (v & 1))) v++;
-        } else {
-            v = (s + 32768) >> 16;
+    // ---- 7x7 Gaussian, row pass (exact, <= 65535), two rows per task, packed vertically ----
+    const uint32_t k0 = (uint32_t)c_gauss[0], k1 = (uint32_t)c_gauss[1], k2 = (uint32_t)c_gauss[2], k3 = (uint32_t)c_gauss[3];
+    const uint32_t KA = k0 | (k1 << 8) | (k2 << 16) | (k3 << 24);     // taps 0..3
+    const uint32_t KB = k2 | (k1 << 8) | (k0 << 16);                  // taps 4..6 (symmetric kernel), tap 7 = 0
+#pragma unroll
+    for (int it = 0; it < 4; it++) {
+        const int t = it * 64 + lane;
+        if (t < DW_P_ROWS * 10) {
+            const int rp = t / 10, gq = t - rp * 10;
+            const uint32_t *ra = reinterpret_cast<const uint32_t *>(&S.raw[(2 * rp) * DW_RAW_STRIDE + 4 * gq]);
+            const uint32_t *rbp = reinterpret_cast<const uint32_t *>(&S.raw[(2 * rp + 1) * DW_RAW_STRIDE + 4 * gq]);
+            const uint32_t a0 = ra[0], a1 = ra[1], a2 = ra[2];
+            const uint32_t b0 = rbp[0], b1 = rbp[1], b2 = rbp[2];
+            uint32_t o[4];
+#define ROWOUT(J, LOW0, LOW1, LOW2)                                                                             \
+    (__builtin_amdgcn_udot4((J) == 0 ? LOW0 : __builtin_amdgcn_alignbyte(LOW1, LOW0, (J)), KA,                  \
+                            __builtin_amdgcn_udot4((J) == 0 ? LOW1 : __builtin_amdgcn_alignbyte(LOW2, LOW1, (J)), KB, 0u, false), false))
+            o[0] = ROWOUT(0, a0, a1, a2) | (ROWOUT(0, b0, b1, b2) << 16);
+            o[1] = ROWOUT(1, a0, a1, a2) | (ROWOUT(1, b0, b1, b2) << 16);
+            o[2] = ROWOUT(2, a0, a1, a2) | (ROWOUT(2, b0, b1, b2) << 16);
+            o[3] = ROWOUT(3, a0, a1, a2) | (ROWOUT(3, b0, b1, b2) << 16);
+#undef ROWOUT
+            *reinterpret_cast<uint4 *>(&S.P[rp * DW_P_STRIDE + 4 * gq]) = make_uint4(o[0], o[1], o[2], o[3]);
         }
-        bl[r * 40 + c] = (uint8_t)min(v, 255);
     }
-    __syncthreads();
+    DSYNC();
 
-    // rBRIEF (:110-149)
+    // ---- column pass: lane = (column pair, block of row pairs); 4 x dot2 per output ----
+    uint8_t *bl = S.raw;   // raw is dead from here on
+    {
+        const uint32_t K01 = k0 | (k1 << 16), K23 = k2 | (k3 << 16), K45 = k2 | (k1 << 16), K6_ = k0;       // even rows
+        const uint32_t K_0 = k0 << 16, K12 = k1 | (k2 << 16), K34 = k3 | (k2 << 16), K56 = k1 | (k0 << 16); // odd rows
+        const int simd_cols = plan.blur_mode == 1 ? (L.w & ~3) : 0;
+        if (lane < 57) {
+            const int blk = lane / 19, cp = lane - blk * 19;          // 3 blocks x 19 column pairs
+            const int q0 = blk == 0 ? 0 : blk == 1 ? 7 : 13;           // row-pair blocks [0,7) [7,13) [13,19)
+            const int nq = blk == 0 ? 7 : 6;
+            const int c = 2 * cp;
+            typedef unsigned short us2 __attribute__((ext_vector_type(2)));
+            uint2 w[4];
+#pragma unroll
+            for (int j = 0; j < 3; j++) w[j + 1] = *reinterpret_cast<const uint2 *>(&S.P[(q0 + j) * DW_P_STRIDE + c]);
+#pragma unroll
+            for (int qi = 0; qi < 7; qi++) {
+                if (qi < nq) {
+                    const int q = q0 + qi;
+                    w[0] = w[1]; w[1] = w[2]; w[2] = w[3];
+                    w[3] = *reinterpret_cast<const uint2 *>(&S.P[(q + 3) * DW_P_STRIDE + c]);
+#define D2(A, K, ACC) __builtin_amdgcn_udot2(__builtin_bit_cast(us2, (A)), __builtin_bit_cast(us2, (uint32_t)(K)), (ACC), false)
+                    const uint32_t e0 = D2(w[0].x, K01, D2(w[1].x, K23, D2(w[2].x, K45, D2(w[3].x, K6_, 0u))));
+                    const uint32_t e1 = D2(w[0].y, K01, D2(w[1].y, K23, D2(w[2].y, K45, D2(w[3].y, K6_, 0u))));
+                    const uint32_t o0 = D2(w[0].x, K_0, D2(w[1].x, K12, D2(w[2].x, K34, D2(w[3].x, K56, 0u))));
+                    const uint32_t o1 = D2(w[0].y, K_0, D2(w[1].y, K12, D2(w[2].y, K34, D2(w[3].y, K56, 0u))));
+#undef D2
+                    uint32_t s4[4] = {e0, e1, o0, o1};
+                    uint32_t v4[4];
+#pragma unroll
+                    for (int z = 0; z < 4; z++) {
+                        const int col = x - DESC_R + c + (z & 1);
+                        uint32_t v;
+                        if (col < simd_cols) {        // OpenCV x86 SSE2 column path: round half to even
+                            v = s4[z] >> 16;
+                            const uint32_t rem = s4[z] & 0xFFFFu;
+                            if (rem > 0x8000u || (rem == 0x8000u && (v & 1u))) v++;
+                        } else {                      // OpenCV portable C path: (sum + 32768) >> 16
+                            v = (s4[z] + 32768u) >> 16;
+                        }
+                        v4[z] = min(v, 255u);
+                    }
+                    *reinterpret_cast<uint16_t *>(&bl[(2 * q) * DW_BL_STRIDE + c]) = (uint16_t)(v4[0] | (v4[1] << 8));
+                    if (2 * q + 1 < DESC_BL)
+                        *reinterpret_cast<uint16_t *>(&bl[(2 * q + 1) * DW_BL_STRIDE + c]) = (uint16_t)(v4[2] | (v4[3] << 8));
+                }
+            }
+        }
+    }
+    DSYNC();
+
+    // ---- rBRIEF (:110-149) ----
     const float factorPI = (float)(3.14159265358979323846 / 180.f);
     float a, b;
     sincos_cr(__fmul_rn(angle, factorPI), &a, &b);
     unsigned long long bits[4];
+    const uint32_t pws[4] = {pw0, pw1, pw2, pw3};
 #pragma unroll
     for (int j = 0; j < 4; j++) {
-        const int pair = j * 64 + lane;
-        const signed char *pp = &c_pattern[pair * 4];
-        const float x0 = (float)pp[0], y0 = (float)pp[1], x1 = (float)pp[2], y1 = (float)pp[3];
-        const int r0 = __float2int_rn(__fadd_rn(__fmul_rn(x0, b), __fmul_rn(y0, a)));
-        const int q0 = __float2int_rn(__fsub_rn(__fmul_rn(x0, a), __fmul_rn(y0, b)));
-        const int r1 = __float2int_rn(__fadd_rn(__fmul_rn(x1, b), __fmul_rn(y1, a)));
-        const int q1 = __float2int_rn(__fsub_rn(__fmul_rn(x1, a), __fmul_rn(y1, b)));
-        const int t0 = bl[(DESC_R + r0) * 40 + DESC_R + q0];
-        const int t1 = bl[(DESC_R + r1) * 40 + DESC_R + q1];
+        const uint32_t pw = pws[j];
+        const float px0 = (float)(int)(signed char)(pw & 0xFF), py0 = (float)(int)(signed char)((pw >> 8) & 0xFF);
+        const float px1 = (float)(int)(signed char)((pw >> 16) & 0xFF), py1 = (float)(int)(signed char)(pw >> 24);
+        const int r0 = __float2int_rn(__fadd_rn(__fmul_rn(px0, b), __fmul_rn(py0, a)));
+        const int q0 = __float2int_rn(__fsub_rn(__fmul_rn(px0, a), __fmul_rn(py0, b)));
+        const int r1 = __float2int_rn(__fadd_rn(__fmul_rn(px1, b), __fmul_rn(py1, a)));
+        const int q1 = __float2int_rn(__fsub_rn(__fmul_rn(px1, a), __fmul_rn(py1, b)));
+        const int t0 = bl[(DESC_R + r0) * DW_BL_STRIDE + DESC_R + q0];
+        const int t1 = bl[(DESC_R + r1) * DW_BL_STRIDE + DESC_R + q1];
         bits[j] = __ballot(t0 < t1);
     }
     const long long o = (long long)f * plan.out_cap + g;
@@ -238,6 +371,8 @@ void orbx_launch_describe(const OrbxPlan &plan, const OrbxWork &wk, int nframes,
                           orbx_keypoint *d_kps, uint8_t *d_desc, int32_t *d_counts,
                           int32_t *d_status, hipStream_t s)
 {
-    dim3 grid(plan.out_cap, nframes);
-    hipLaunchKernelGGL(k_describe, grid, dim3(DESC_THREADS), 0, s, plan, wk, d_kps, d_desc, d_counts, d_status);
+    const OrbxLevel &L0 = plan.lv[0];
+    const int l0_aligned = (((uintptr_t)L0.base | (uintptr_t)L0.stride | (uintptr_t)L0.frame_stride) & 3) == 0;
+    dim3 grid((plan.out_cap + 3) / 4, nframes);
+    hipLaunchKernelGGL(k_describe, grid, dim3(256), 0, s, plan, wk, d_kps, d_desc, d_counts, d_status, l0_aligned);
 }
