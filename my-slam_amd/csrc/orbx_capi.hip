@@ -144,12 +144,12 @@ static int make_plan(const orbx_extractor *h, int W, int H, OrbxPlan *P, std::st
 }
 
 // cv::resize INTER_LINEAR planning for one level pair (OpenCV 3.1.0 imgwarp.cpp)
-static void plan_resize(int sw, int sh, int dw, int dh, int *xofs, short2 *alpha, int *yofs, short2 *beta, int *area2)
+static void plan_resize(int sw, int sh, int dw, int dh, int *xofs, short2 *alpha, int *yofs, short2 *beta, int *mode)
 {
     const double inv_x = (double)dw / sw, inv_y = (double)dh / sh;
     const double scale_x = 1. / inv_x, scale_y = 1. / inv_y;
     const int isx = cv_round(scale_x), isy = cv_round(scale_y);
-    *area2 = fabs(scale_x - isx) < DBL_EPSILON && fabs(scale_y - isy) < DBL_EPSILON && isx == 2 && isy == 2;
+    const bool area2 = fabs(scale_x - isx) < DBL_EPSILON && fabs(scale_y - isy) < DBL_EPSILON && isx == 2 && isy == 2;
     auto sat = [](float v) { int i = cv_round(v); return (short)(i < -32768 ? -32768 : i > 32767 ? 32767 : i); };
     for (int dx = 0; dx < dw; dx++) {
         float fx = (float)((dx + 0.5) * scale_x - 0.5);
@@ -167,6 +167,10 @@ static void plan_resize(int sw, int sh, int dw, int dh, int *xofs, short2 *alpha
         yofs[dy] = sy;
         beta[dy] = make_short2(sat((1.f - fy) * 2048), sat(fy * 2048));
     }
+    // the 4x4 kernel moves 8 source bytes per 4 destination columns: needs xofs[x+3]+1 - xofs[x] <= 7
+    int span = 0;
+    for (int dx = 0; dx + 3 < dw; dx += 4) span = std::max(span, xofs[dx + 3] + 1 - xofs[dx]);
+    *mode = area2 ? RESIZE_AREA2 : (span <= 7 && sw >= 12 ? RESIZE_FAST : RESIZE_GENERIC);
 }
 
 static void free_all(orbx_extractor *h)
@@ -221,16 +225,16 @@ extern "C" int orbx_create(orbx_extractor **out, int nfeatures, float scale_fact
     const size_t B = (size_t)max_batch;
     h->in_stride = (int)align_up(max_width, 64);
     h->in_frame = align_up((size_t)h->in_stride * max_height, 256);
-    ALLOC(h->d_input, B * h->in_frame);
+    ALLOC(h->d_input, B * h->in_frame + 256);
     size_t off = 0, tab_e = 0;
     for (int l = 1; l < nlevels; l++) {
         const OrbxLevel &L = h->max_plan.lv[l];
         h->pyr_level_off[l] = off;
         off += B * align_up(align_up(L.w, 64) * (size_t)L.h, 256);
-        tab_e += (size_t)L.w + L.h;
+        tab_e += align_up((size_t)L.w + 4, 4) + align_up((size_t)L.h + 4, 4);
     }
     h->pyr_bytes = off; h->tab_elems = tab_e;
-    ALLOC(h->d_pyr, off);
+    ALLOC(h->d_pyr, off + 256);   // slack: the 4x4 resize reads whole dwords around a row segment
     ALLOC(h->d_tab_i, tab_e * sizeof(int));
     ALLOC(h->d_tab_s, tab_e * sizeof(short2));
     const OrbxPlan &M = h->max_plan;
@@ -326,10 +330,11 @@ static int ensure_plan(orbx_extractor *h, int W, int H)
         L.frame_stride = (long long)align_up((size_t)L.stride * L.h, 256);
         L.base = h->d_pyr + h->pyr_level_off[l];
         const OrbxLevel &S = P.lv[l - 1];
-        plan_resize(S.w, S.h, L.w, L.h, &ti[e], &ts[e], &ti[e + L.w], &ts[e + L.w], &h->area2[l]);
+        const size_t ex = align_up((size_t)L.w + 4, 4), ey = align_up((size_t)L.h + 4, 4);
+        plan_resize(S.w, S.h, L.w, L.h, &ti[e], &ts[e], &ti[e + ex], &ts[e + ex], &h->area2[l]);
         h->tabs[l].xofs = h->d_tab_i + e; h->tabs[l].alpha = h->d_tab_s + e;
-        h->tabs[l].yofs = h->d_tab_i + e + L.w; h->tabs[l].beta = h->d_tab_s + e + L.w;
-        e += (size_t)L.w + L.h;
+        h->tabs[l].yofs = h->d_tab_i + e + ex; h->tabs[l].beta = h->d_tab_s + e + ex;
+        e += ex + ey;
     }
     HIPCHK(hipStreamSynchronize(h->stream));
     HIPCHK(hipMemcpy(h->d_tab_i, ti.data(), e * sizeof(int), hipMemcpyHostToDevice));
@@ -357,7 +362,12 @@ static int enqueue(orbx_extractor *h, const uint8_t *d_images, int nframes, int 
     HIPCHK(hipMemsetAsync(h->work.cand_count, 0, (size_t)nframes * h->nlevels * sizeof(uint32_t), s));
     HIPCHK(hipMemsetAsync(h->work.errflags, 0, (size_t)nframes * sizeof(uint32_t), s));
     if (prof) HIPCHK(hipEventRecord(h->ev[0], s));
-    for (int l = 1; l < h->nlevels; l++) orbx_launch_resize(P.lv[l - 1], P.lv[l], h->tabs[l], h->area2[l], nframes, s);
+    for (int l = 1; l < h->nlevels; l++) {
+        const uint8_t *src_end = nullptr;   // level 0 in caller memory has no slack behind its last byte
+        if (l == 1 && d_images != h->d_input)
+            src_end = d_images + (long long)(nframes - 1) * frame_stride + (long long)(H - 1) * row_stride + W;
+        orbx_launch_resize(P.lv[l - 1], P.lv[l], h->tabs[l], h->area2[l], nframes, src_end, s);
+    }
     if (prof) HIPCHK(hipEventRecord(h->ev[1], s));
     orbx_launch_fast(P, h->work, nframes, s);
     if (prof) HIPCHK(hipEventRecord(h->ev[2], s));

@@ -23,23 +23,47 @@
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); \
     } while (0)
 
+#define FAST_PADL 4      // left pad (bytes) of every tile row so that dword g-1 exists for every group
+#define FAST_CLIST 256   // corners listed per cell before NMS falls back to scanning the whole score map
+
 template <int TS, int TH, int ZS>   // tile row stride (bytes, multiple of 4), tile rows, score-map stride/rows
 struct FastLds {
     uint8_t tile[TS * TH];
     uint8_t smap[ZS * ZS];
     uint16_t queue[128];
+    uint16_t clist[FAST_CLIST];
     unsigned long long masks[(ZS * ZS + 63) / 64];
 };
 
-__device__ __forceinline__ int cls8(int a, int lo, int hi) { return ((a < lo) ? 1 : 0) | ((a > hi) ? 2 : 0); }
+typedef unsigned short us2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ us2 as_us2(uint32_t v) { return __builtin_bit_cast(us2, v); }
+__device__ __forceinline__ uint32_t as_u32(us2 v) { return __builtin_bit_cast(uint32_t, v); }
+__device__ __forceinline__ us2 lo2(uint32_t d) { return as_us2(__builtin_amdgcn_perm(0u, d, 0x0c010c00u)); }   // bytes 0,1 -> u16 x2
+__device__ __forceinline__ us2 hi2(uint32_t d) { return as_us2(__builtin_amdgcn_perm(0u, d, 0x0c030c02u)); }   // bytes 2,3 -> u16 x2
 
-// stage 2 for up to 64 queued survivors: full 16-pixel arc test and corner score
-template <int TS>
-__device__ __forceinline__ void fast_stage2(const uint8_t *T0, const uint16_t *queue, uint8_t *smap, int cnt,
-                                            int lane, int t_lo, int sms)
+// 8-point reject for two pixels at once (u16 lanes).  A 9-arc holds one pixel of each opposite pair
+// and all its pixels are on one side, so a corner needs  v - t > max_k min(p_k, p_k+8)  (all four pairs
+// have a darker member) or  v + t < min_k max(p_k, p_k+8).  Returns non-zero u16 lanes where it holds.
+__device__ __forceinline__ uint32_t reject8(us2 c, us2 t, us2 a0, us2 a8, us2 a4, us2 a12, us2 a2, us2 a10, us2 a6, us2 a14)
 {
-    if (lane >= cnt) return;
+    const us2 mlo = __builtin_elementwise_max(__builtin_elementwise_max(__builtin_elementwise_min(a0, a8), __builtin_elementwise_min(a4, a12)),
+                                              __builtin_elementwise_max(__builtin_elementwise_min(a2, a10), __builtin_elementwise_min(a6, a14)));
+    const us2 mhi = __builtin_elementwise_min(__builtin_elementwise_min(__builtin_elementwise_max(a0, a8), __builtin_elementwise_max(a4, a12)),
+                                              __builtin_elementwise_min(__builtin_elementwise_max(a2, a10), __builtin_elementwise_max(a6, a14)));
+    const us2 dark = __builtin_elementwise_sub_sat(__builtin_elementwise_sub_sat(c, t), mlo);
+    const us2 bright = __builtin_elementwise_sub_sat(mhi, c + t);
+    return as_u32(dark) | as_u32(bright);
+}
+
+// stage 2 for up to 64 queued survivors: corner score = max over the 16 nine-arcs of min(d) / min(-d),
+// minus 1; the pixel is a corner at threshold t  <=>  score >= t, so no separate arc test is needed.
+template <int TS>
+__device__ __forceinline__ bool fast_stage2(const uint8_t *T0, const uint16_t *queue, uint8_t *smap, int cnt,
+                                            int lane, int t_lo, int sms, int *pos_out)
+{
+    if (lane >= cnt) return false;
     const int pos = queue[lane];
+    *pos_out = pos;
     const int y = pos >> 6, x = pos & 63;
     const uint8_t *p = T0 + (y + 3) * TS + x + 3;
     const int v = p[0];
@@ -48,18 +72,6 @@ __device__ __forceinline__ void fast_stage2(const uint8_t *T0, const uint16_t *q
     d[4] = v - p[3];            d[5] = v - p[-1 * TS + 3];  d[6] = v - p[-2 * TS + 2];  d[7] = v - p[-3 * TS + 1];
     d[8] = v - p[-3 * TS];      d[9] = v - p[-3 * TS - 1];  d[10] = v - p[-2 * TS - 2]; d[11] = v - p[-1 * TS - 3];
     d[12] = v - p[-3];          d[13] = v - p[1 * TS - 3];  d[14] = v - p[2 * TS - 2];  d[15] = v - p[3 * TS - 1];
-    uint32_t dm = 0, bm = 0;   // darker: p_k < v - t <=> d > t ; brighter: d < -t
-#pragma unroll
-    for (int k = 0; k < 16; k++) {
-        dm |= (d[k] > t_lo ? 1u : 0u) << k;
-        bm |= (d[k] < -t_lo ? 1u : 0u) << k;
-    }
-    uint32_t m2 = dm | (dm << 16), r = m2 & (m2 >> 1);   // 9 contiguous set bits on the circular mask
-    r &= r >> 2; r &= r >> 4; r &= m2 >> 8;
-    uint32_t n2 = bm | (bm << 16), q = n2 & (n2 >> 1);
-    q &= q >> 2; q &= q >> 4; q &= n2 >> 8;
-    if (((r | q) & 0xFFFFu) == 0) return;
-    // dark arcs: max over the 16 starts of min(d[s..s+8]); bright arcs: min over starts of max(...)
     int A = -256, B = 256;
     {
         int a2[16], a4[16];
@@ -79,7 +91,10 @@ __device__ __forceinline__ void fast_stage2(const uint8_t *T0, const uint16_t *q
 #pragma unroll
         for (int k = 0; k < 16; k++) B = min(B, max(max(b4[k], b4[(k + 4) & 15]), d[(k + 8) & 15]));
     }
-    smap[(y + 1) * sms + x + 1] = (uint8_t)(max(A, -B) - 1);   // >= t_lo for a corner, <= 254
+    const int score = max(A, -B) - 1;     // <= 254
+    if (score < t_lo) return false;
+    smap[(y + 1) * sms + x + 1] = (uint8_t)score;
+    return true;
 }
 
 template <int TS, int TH, int ZS>
@@ -112,20 +127,21 @@ __global__ __launch_bounds__(FAST_THREADS) void k_fast_cells(OrbxPlan plan, Orbx
     // ---- tile -> LDS.  Rows start at a 4-byte aligned address of the level (levels >= 1 always;
     // level 0 when the caller's base/strides are 4-byte multiples), so whole dwords are moved. ----
     const uint8_t *img = L.base + (long long)f * L.frame_stride + (long long)iniY * L.stride;
-    const int xoff = (l == 0 && !l0_aligned) ? 0 : (iniX & 3);
-    if (l == 0 && !l0_aligned) {
+    const bool bytes_only = (l == 0 && !l0_aligned);
+    const int xoff = bytes_only ? 0 : (iniX & 3);
+    if (bytes_only) {
         for (int i = lane; i < tw * th; i += 64) {
             const int y = i / tw, x = i - y * tw;
-            S.tile[y * TS + x] = img[(long long)y * L.stride + iniX + x];
+            S.tile[y * TS + FAST_PADL + x] = img[(long long)y * L.stride + iniX + x];
         }
     } else {
-        constexpr int NDW = TS / 4, RPP = 64 / NDW;   // dwords per tile row, rows per pass
+        constexpr int NDW = TS / 4 - 2, RPP = 64 / NDW;   // payload dwords per tile row, rows per pass
         const int ndw = (xoff + tw + 3) >> 2;
         const int r_in = lane / NDW, cdw = lane - r_in * NDW;
         const uint8_t *src = img + (iniX & ~3) + 4 * cdw;
         if (r_in < RPP && cdw < ndw) {
             for (int r = r_in; r < th; r += RPP)
-                *reinterpret_cast<uint32_t *>(&S.tile[r * TS + 4 * cdw]) =
+                *reinterpret_cast<uint32_t *>(&S.tile[r * TS + FAST_PADL + 4 * cdw]) =
                     *reinterpret_cast<const uint32_t *>(src + (long long)r * L.stride);
         }
     }
@@ -135,54 +151,91 @@ __global__ __launch_bounds__(FAST_THREADS) void k_fast_cells(OrbxPlan plan, Orbx
         for (int i = lane; i < nz; i += 64) z[i] = 0;
     }
     WSYNC();
-    const uint8_t *T0 = S.tile + xoff;   // tile origin (cell column 0)
+    const uint8_t *T0 = S.tile + FAST_PADL + xoff;   // tile origin (cell column 0)
 
-    // ---- stages 1+2 ----
-    int qn = 0;
-    for (int base = 0; base < npx; base += 64) {
-        const int idx = base + lane;
-        bool pass = false;
-        int y = 0, x = 0;
-        if (idx < npx) {
-            y = (int)(((uint32_t)idx * rcp) >> 20);
-            x = idx - y * zw;
-            const uint8_t *p = T0 + (y + 3) * TS + x + 3;
-            const int v = p[0], lo = v - t_lo, hi = v + t_lo;
-            int d = cls8(p[3 * TS], lo, hi) | cls8(p[-3 * TS], lo, hi);                 // pixels 0, 8
-            d &= cls8(p[3], lo, hi) | cls8(p[-3], lo, hi);                               // 4, 12
-            d &= cls8(p[2 * TS + 2], lo, hi) | cls8(p[-2 * TS - 2], lo, hi);             // 2, 10
-            d &= cls8(p[-2 * TS + 2], lo, hi) | cls8(p[2 * TS - 2], lo, hi);             // 6, 14
-            pass = d != 0;
+    // ---- stages 1+2.  Stage-1 task = (zone row, dword group): 4 horizontally adjacent pixels ----
+    const int cb = FAST_PADL + xoff + 3;                 // tile byte column of zone column 0
+    const int g0 = cb >> 2, ng = ((cb + zw - 1) >> 2) - g0 + 1;
+    const uint32_t rcpg = (1u << 16) / (uint32_t)ng + 1u;    // t / ng for t < 1024, ng <= 16
+    const int ntask = ng * zh;
+    const us2 tt = as_us2((uint32_t)t_lo * 0x00010001u);
+    int qn = 0, ncl = 0;
+    bool cl_over = false;
+    for (int base = 0; base < ntask; base += 64) {
+        const int t = base + lane;
+        uint32_t f01 = 0, f23 = 0;
+        int zy = 0, zx0 = 0;
+        if (t < ntask) {
+            zy = (int)(((uint32_t)t * rcpg) >> 16);
+            const int g = g0 + (t - zy * ng);
+            zx0 = 4 * g - cb;                                    // zone column of byte 0 of this group
+            const uint32_t *r0 = reinterpret_cast<const uint32_t *>(&S.tile[(zy + 3) * TS]) + g;
+            const uint32_t *rp = reinterpret_cast<const uint32_t *>(&S.tile[(zy + 5) * TS]) + g;
+            const uint32_t *rm = reinterpret_cast<const uint32_t *>(&S.tile[(zy + 1) * TS]) + g;
+            const uint32_t dD = *(reinterpret_cast<const uint32_t *>(&S.tile[(zy + 6) * TS]) + g);   // pixel 0  (0,+3)
+            const uint32_t dU = *(reinterpret_cast<const uint32_t *>(&S.tile[(zy + 0) * TS]) + g);   // pixel 8  (0,-3)
+            const uint32_t cL = r0[-1], cC = r0[0], cR = r0[1];
+            const uint32_t pL = rp[-1], pC = rp[0], pR = rp[1];
+            const uint32_t mL = rm[-1], mC = rm[0], mR = rm[1];
+            const uint32_t d4 = __builtin_amdgcn_alignbyte(cR, cC, 3);    // pixel 4  (+3, 0)
+            const uint32_t d12 = __builtin_amdgcn_alignbyte(cC, cL, 1);   // pixel 12 (-3, 0)
+            const uint32_t d2 = __builtin_amdgcn_alignbyte(pR, pC, 2);    // pixel 2  (+2,+2)
+            const uint32_t d14 = __builtin_amdgcn_alignbyte(pC, pL, 2);   // pixel 14 (-2,+2)
+            const uint32_t d6 = __builtin_amdgcn_alignbyte(mR, mC, 2);    // pixel 6  (+2,-2)
+            const uint32_t d10 = __builtin_amdgcn_alignbyte(mC, mL, 2);   // pixel 10 (-2,-2)
+            f01 = reject8(lo2(cC), tt, lo2(dD), lo2(dU), lo2(d4), lo2(d12), lo2(d2), lo2(d10), lo2(d6), lo2(d14));
+            f23 = reject8(hi2(cC), tt, hi2(dD), hi2(dU), hi2(d4), hi2(d12), hi2(d2), hi2(d10), hi2(d6), hi2(d14));
         }
-        const unsigned long long m = __ballot(pass);
-        if (pass) S.queue[qn + __popcll(m & ((1ull << lane) - 1ull))] = (uint16_t)((y << 6) | x);
-        qn += __popcll(m);
-        if (qn >= 64) {
-            WSYNC();
-            fast_stage2<TS>(T0, S.queue, S.smap, 64, lane, t_lo, sms);
-            // move the tail of the queue to the front
-            const int rest = qn - 64;
-            uint16_t tmpq = 0;
-            if (lane < rest) tmpq = S.queue[64 + lane];
-            WSYNC();
-            if (lane < rest) S.queue[lane] = tmpq;
-            qn = rest;
-            WSYNC();
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const uint32_t fl = (j < 2 ? f01 : f23) & ((j & 1) ? 0xFFFF0000u : 0x0000FFFFu);
+            const int zx = zx0 + j;
+            const bool pass = fl != 0 && zx >= 0 && zx < zw;
+            const unsigned long long m = __ballot(pass);
+            if (pass) S.queue[qn + __popcll(m & ((1ull << lane) - 1ull))] = (uint16_t)((zy << 6) | zx);
+            qn += __popcll(m);
+            if (qn >= 64) {
+                WSYNC();
+                int pos = 0;
+                const bool corner = fast_stage2<TS>(T0, S.queue, S.smap, 64, lane, t_lo, sms, &pos);
+                const unsigned long long cm = __ballot(corner);
+                const int nc = __popcll(cm);
+                if (ncl + nc <= FAST_CLIST) { if (corner) S.clist[ncl + __popcll(cm & ((1ull << lane) - 1ull))] = (uint16_t)pos; ncl += nc; }
+                else cl_over = true;
+                const int rest = qn - 64;            // move the tail of the queue to the front
+                uint16_t tmpq = 0;
+                if (lane < rest) tmpq = S.queue[64 + lane];
+                WSYNC();
+                if (lane < rest) S.queue[lane] = tmpq;
+                qn = rest;
+                WSYNC();
+            }
         }
     }
     WSYNC();
-    fast_stage2<TS>(T0, S.queue, S.smap, qn, lane, t_lo, sms);   // the remaining survivors
+    {   // the remaining survivors
+        int pos = 0;
+        const bool corner = fast_stage2<TS>(T0, S.queue, S.smap, qn, lane, t_lo, sms, &pos);
+        const unsigned long long cm = __ballot(corner);
+        const int nc = __popcll(cm);
+        if (ncl + nc <= FAST_CLIST) { if (corner) S.clist[ncl + __popcll(cm & ((1ull << lane) - 1ull))] = (uint16_t)pos; ncl += nc; }
+        else cl_over = true;
+    }
     WSYNC();
 
-    // ---- stage 3: NMS (strictly greater than all 8 neighbours; outside the cell zone counts as 0) ----
+    // ---- stage 3: NMS (strictly greater than all 8 neighbours; outside the cell zone counts as 0).
+    // Items are the listed corners, or every zone pixel if the list overflowed. ----
     int n_ini = 0, n_min = 0;
-    const int niter = (npx + 63) >> 6;
+    const int nitem = cl_over ? npx : ncl;
+    const int niter = (nitem + 63) >> 6;
     for (int it = 0; it < niter; it++) {
         const int idx = it * 64 + lane;
         bool ismax = false;
         int s = 0;
-        if (idx < npx) {
-            const int y = (int)(((uint32_t)idx * rcp) >> 20), x = idx - y * zw;
+        if (idx < nitem) {
+            int y, x;
+            if (cl_over) { y = (int)(((uint32_t)idx * rcp) >> 20); x = idx - y * zw; }
+            else { const int pos = S.clist[idx]; y = pos >> 6; x = pos & 63; }
             const uint8_t *q = &S.smap[(y + 1) * sms + x + 1];
             s = q[0];
             if (s > 0)
@@ -211,8 +264,8 @@ __global__ __launch_bounds__(FAST_THREADS) void k_fast_cells(OrbxPlan plan, Orbx
         bool emit = false;
         int y = 0, x = 0, s = 0;
         if ((mm >> lane) & 1ull) {
-            y = (int)(((uint32_t)idx * rcp) >> 20);
-            x = idx - y * zw;
+            if (cl_over) { y = (int)(((uint32_t)idx * rcp) >> 20); x = idx - y * zw; }
+            else { const int pos = S.clist[idx]; y = pos >> 6; x = pos & 63; }
             s = S.smap[(y + 1) * sms + x + 1];
             emit = s >= t_use;
         }
@@ -241,8 +294,8 @@ void orbx_launch_fast(const OrbxPlan &plan, const OrbxWork &wk, int nframes, hip
     const OrbxLevel &L0 = plan.lv[0];
     const int l0_aligned = (((uintptr_t)L0.base | (uintptr_t)L0.stride | (uintptr_t)L0.frame_stride) & 3) == 0;
     dim3 grid((plan.ncells + FAST_THREADS / 64 - 1) / (FAST_THREADS / 64), nframes);
-    if (maxcell <= 38)   // tile <= 44x44, zone <= 38x38
-        hipLaunchKernelGGL((k_fast_cells<48, 44, 40>), grid, dim3(FAST_THREADS), 0, s, plan, wk, l0_aligned);
+    if (maxcell <= 38)   // tile <= 44x44, zone <= 38x38; row = 4 pad + 3 + 44 + over-read -> 56 B
+        hipLaunchKernelGGL((k_fast_cells<56, 44, 40>), grid, dim3(FAST_THREADS), 0, s, plan, wk, l0_aligned);
     else                 // cells of tiny levels: tile <= 66x66, zone <= 60x60
-        hipLaunchKernelGGL((k_fast_cells<72, 66, 64>), grid, dim3(FAST_THREADS), 0, s, plan, wk, l0_aligned);
+        hipLaunchKernelGGL((k_fast_cells<80, 66, 64>), grid, dim3(FAST_THREADS), 0, s, plan, wk, l0_aligned);
 }

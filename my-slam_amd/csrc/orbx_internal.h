@@ -78,8 +78,10 @@ struct ResizeTab {                // per destination level
 };
 
 // ---- launchers (orbx_kernels.hip) ----
-void orbx_launch_resize(const OrbxLevel &src, const OrbxLevel &dst, const ResizeTab &tab, int area2,
-                        int nframes, hipStream_t s);
+enum { RESIZE_FAST = 0, RESIZE_AREA2 = 1, RESIZE_GENERIC = 2 };
+// src_end != NULL: the source is caller-owned memory; one past its last valid byte (fast path guard)
+void orbx_launch_resize(const OrbxLevel &src, const OrbxLevel &dst, const ResizeTab &tab, int mode,
+                        int nframes, const uint8_t *src_end, hipStream_t s);
 void orbx_launch_fast(const OrbxPlan &plan, const OrbxWork &wk, int nframes, hipStream_t s);
 void orbx_launch_octree(const OrbxPlan &plan, const OrbxWork &wk, int nframes, size_t lds_bytes,
                         hipStream_t s);

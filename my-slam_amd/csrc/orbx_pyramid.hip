@@ -52,18 +52,100 @@ __global__ __launch_bounds__(256) void k_resize_area2(
         (uint8_t)((s0[0] + s0[1] + s1[0] + s1[1] + 2) >> 2);
 }
 
-void orbx_launch_resize(const OrbxLevel &src, const OrbxLevel &dst, const ResizeTab &tab, int area2,
-                        int nframes, hipStream_t s)
+// -------------------------------------------------------------------------------------------------
+// Fast path: one thread = a 4x4 block of destination pixels.  The four columns' source offsets and
+// 11-bit coefficients are loaded once (two 16-byte table reads) and reused for four rows; each source
+// row segment (<= 8 bytes for scale factors up to 2) arrives as three aligned dwords that are
+// funnel-shifted into place, so there are 1.5 memory instructions per destination pixel instead of
+// 6, and the horizontal blend is one v_dot2_u32_u16.  CHECK guards the last bytes of a caller-owned
+// level-0 buffer, which has no slack behind it.
+// -------------------------------------------------------------------------------------------------
+template <bool CHECK>
+__global__ __launch_bounds__(256) void k_resize_linear_4x4(
+    const uint8_t *__restrict__ src, int sw, int sh, int sstride, long long sframe,
+    uint8_t *__restrict__ dst, int dw, int dh, int dstride, long long dframe, ResizeTab tab,
+    const uint8_t *src_end)
 {
-    dim3 block(64, 4);
-    if (area2) {
-        dim3 grid((dst.w + 63) / 64, (dst.h + 3) / 4, nframes);
-        hipLaunchKernelGGL(k_resize_area2, grid, block, 0, s, src.base, src.stride, src.frame_stride,
-                           dst.base, dst.w, dst.h, dst.stride, dst.frame_stride);
-    } else {
-        dim3 grid((dst.w + 255) / 256, (dst.h + 3) / 4, nframes);
-        hipLaunchKernelGGL(k_resize_linear, grid, block, 0, s, src.base, src.w, src.h, src.stride,
-                           src.frame_stride, dst.base, dst.w, dst.h, dst.stride, dst.frame_stride, tab);
+    typedef unsigned short us2 __attribute__((ext_vector_type(2)));
+    const int x4 = (blockIdx.x * 32 + threadIdx.x) * 4;
+    const int y4 = (blockIdx.y * 8 + threadIdx.y) * 4;
+    if (x4 >= dw || y4 >= dh) return;
+    const uint8_t *S = src + (long long)blockIdx.z * sframe;
+    uint8_t *D = dst + (long long)blockIdx.z * dframe;
+
+    const int4 sxv = *reinterpret_cast<const int4 *>(tab.xofs + x4);          // tables are padded to 4
+    const uint4 alv = *reinterpret_cast<const uint4 *>(tab.alpha + x4);        // (a0 | a1 << 16) per column
+    int sx[4] = {sxv.x, sxv.y, sxv.z, sxv.w};
+    uint32_t al[4] = {alv.x, alv.y, alv.z, alv.w};
+#pragma unroll
+    for (int i = 1; i < 4; i++)
+        if (x4 + i >= dw) { sx[i] = sx[0]; al[i] = al[0]; }
+    const int base = sx[0];
+    const int k1 = 8 * (sx[1] - base), k2 = 8 * (sx[2] - base), k3 = 8 * (sx[3] - base);
+
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+        const int y = y4 + r;
+        if (y >= dh) break;
+        const int sy = tab.yofs[y];
+        const uint32_t bw = *reinterpret_cast<const uint32_t *>(tab.beta + y);
+        const int b0 = (int)(short)(bw & 0xFFFFu), b1 = (int)(short)(bw >> 16);
+        const int sy0 = min(max(sy, 0), sh - 1), sy1 = min(max(sy + 1, 0), sh - 1);
+        int hv[2][4];
+#pragma unroll
+        for (int rr = 0; rr < 2; rr++) {
+            const uint8_t *p = S + (long long)(rr ? sy1 : sy0) * sstride + base;
+            const uint32_t sh8 = (uint32_t)((uintptr_t)p & 3u);
+            const uint32_t *q = reinterpret_cast<const uint32_t *>(p - sh8);
+            uint32_t w0, w1, w2;
+            if (CHECK) {
+                w0 = q[0];
+                w1 = (reinterpret_cast<const uint8_t *>(q + 2) <= src_end) ? q[1] : 0u;
+                w2 = (reinterpret_cast<const uint8_t *>(q + 3) <= src_end) ? q[2] : 0u;
+            } else {
+                w0 = q[0]; w1 = q[1]; w2 = q[2];
+            }
+            const uint32_t lo = __builtin_amdgcn_alignbyte(w1, w0, sh8);
+            const uint32_t hi = __builtin_amdgcn_alignbyte(w2, w1, sh8);
+            const unsigned long long w64 = ((unsigned long long)hi << 32) | lo;
+            const uint32_t t0 = lo, t1 = (uint32_t)(w64 >> k1), t2 = (uint32_t)(w64 >> k2), t3 = (uint32_t)(w64 >> k3);
+            // (S[sx] | S[sx+1] << 16) . (a0 | a1 << 16)
+            hv[rr][0] = (int)__builtin_amdgcn_udot2(__builtin_bit_cast(us2, __builtin_amdgcn_perm(0u, t0, 0x0c010c00u)), __builtin_bit_cast(us2, al[0]), 0u, false);
+            hv[rr][1] = (int)__builtin_amdgcn_udot2(__builtin_bit_cast(us2, __builtin_amdgcn_perm(0u, t1, 0x0c010c00u)), __builtin_bit_cast(us2, al[1]), 0u, false);
+            hv[rr][2] = (int)__builtin_amdgcn_udot2(__builtin_bit_cast(us2, __builtin_amdgcn_perm(0u, t2, 0x0c010c00u)), __builtin_bit_cast(us2, al[2]), 0u, false);
+            hv[rr][3] = (int)__builtin_amdgcn_udot2(__builtin_bit_cast(us2, __builtin_amdgcn_perm(0u, t3, 0x0c010c00u)), __builtin_bit_cast(us2, al[3]), 0u, false);
+        }
+        uint32_t out = 0;
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            const int v = (((b0 * (hv[0][i] >> 4)) >> 16) + ((b1 * (hv[1][i] >> 4)) >> 16) + 2) >> 2;
+            out |= (uint32_t)(v & 255) << (8 * i);
+        }
+        uint8_t *Dr = D + (long long)y * dstride + x4;
+        if (x4 + 3 < dw) *reinterpret_cast<uint32_t *>(Dr) = out;
+        else
+            for (int i = 0; x4 + i < dw; i++) Dr[i] = (uint8_t)(out >> (8 * i));
     }
 }
 
+void orbx_launch_resize(const OrbxLevel &src, const OrbxLevel &dst, const ResizeTab &tab, int mode,
+                        int nframes, const uint8_t *src_end, hipStream_t s)
+{
+    if (mode == RESIZE_AREA2) {
+        dim3 grid((dst.w + 63) / 64, (dst.h + 3) / 4, nframes);
+        hipLaunchKernelGGL(k_resize_area2, grid, dim3(64, 4), 0, s, src.base, src.stride, src.frame_stride,
+                           dst.base, dst.w, dst.h, dst.stride, dst.frame_stride);
+    } else if (mode == RESIZE_GENERIC) {
+        dim3 grid((dst.w + 255) / 256, (dst.h + 3) / 4, nframes);
+        hipLaunchKernelGGL(k_resize_linear, grid, dim3(64, 4), 0, s, src.base, src.w, src.h, src.stride,
+                           src.frame_stride, dst.base, dst.w, dst.h, dst.stride, dst.frame_stride, tab);
+    } else {
+        dim3 grid((dst.w + 127) / 128, (dst.h + 31) / 32, nframes);
+        if (src_end)
+            hipLaunchKernelGGL(k_resize_linear_4x4<true>, grid, dim3(32, 8), 0, s, src.base, src.w, src.h, src.stride,
+                               src.frame_stride, dst.base, dst.w, dst.h, dst.stride, dst.frame_stride, tab, src_end);
+        else
+            hipLaunchKernelGGL(k_resize_linear_4x4<false>, grid, dim3(32, 8), 0, s, src.base, src.w, src.h, src.stride,
+                               src.frame_stride, dst.base, dst.w, dst.h, dst.stride, dst.frame_stride, tab, src_end);
+    }
+}
