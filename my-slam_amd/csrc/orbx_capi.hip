@@ -242,7 +242,7 @@ extern "C" int orbx_create(orbx_extractor **out, int nfeatures, float scale_fact
     ALLOC(h->work.owner, B * M.cand_frame * sizeof(uint32_t));
     ALLOC(h->work.arena, B * M.arena_frame * sizeof(OrbxNode));
     ALLOC(h->work.sel, B * M.list_frame * sizeof(OrbxCand));
-    ALLOC(h->work.cand_count, B * ORBX_MAX_LEVELS * sizeof(uint32_t));
+    ALLOC(h->work.cand_count, B * ORBX_MAX_LEVELS * ORBX_CNT_STRIDE * sizeof(uint32_t));
     ALLOC(h->work.nk, B * ORBX_MAX_LEVELS * sizeof(uint32_t));
     ALLOC(h->work.errflags, B * sizeof(uint32_t));
     ALLOC(h->d_kps, B * M.out_cap * sizeof(orbx_keypoint));
@@ -353,13 +353,14 @@ static int enqueue(orbx_extractor *h, const uint8_t *d_images, int nframes, int 
     if (rc != ORBX_OK) return rc;
     OrbxPlan &P = h->plan;
     P.blur_mode = h->blur_mode;
+    { const char *e = getenv("ORBX_DBG_STAGE"); P.dbg = e ? atoi(e) : 0; }
     P.lv[0].base = const_cast<uint8_t *>(d_images);
     P.lv[0].stride = row_stride;
     P.lv[0].frame_stride = frame_stride;
     h->last_input = d_images; h->last_in_stride = row_stride; h->last_in_frame = frame_stride; h->last_batch = nframes;
 
     const bool prof = h->profiling != 0;
-    HIPCHK(hipMemsetAsync(h->work.cand_count, 0, (size_t)nframes * h->nlevels * sizeof(uint32_t), s));
+    HIPCHK(hipMemsetAsync(h->work.cand_count, 0, (size_t)nframes * h->nlevels * ORBX_CNT_STRIDE * sizeof(uint32_t), s));
     HIPCHK(hipMemsetAsync(h->work.errflags, 0, (size_t)nframes * sizeof(uint32_t), s));
     if (prof) HIPCHK(hipEventRecord(h->ev[0], s));
     for (int l = 1; l < h->nlevels; l++) {
@@ -503,7 +504,7 @@ extern "C" int orbx_download_candidates(orbx_extractor *h, int frame, int level,
     HIPCHK(hipSetDevice(h->device));
     HIPCHK(hipStreamSynchronize(h->stream));
     uint32_t n = 0;
-    HIPCHK(hipMemcpy(&n, h->work.cand_count + (size_t)frame * h->nlevels + level, sizeof(n), hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(&n, h->work.cand_count + ((size_t)frame * h->nlevels + level) * ORBX_CNT_STRIDE, sizeof(n), hipMemcpyDeviceToHost));
     const OrbxLevel &L = h->plan.lv[level];
     n = std::min<uint32_t>(n, (uint32_t)L.cand_cap);
     if ((int)n > cap) return fail(ORBX_E_CAPACITY, "%u candidates, capacity %d", n, cap);

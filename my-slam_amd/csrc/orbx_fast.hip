@@ -30,7 +30,7 @@ template <int TS, int TH, int ZS>   // tile row stride (bytes, multiple of 4), t
 struct FastLds {
     uint8_t tile[TS * TH];
     uint8_t smap[ZS * ZS];
-    uint16_t queue[128];
+    uint16_t queue[256];
     uint16_t clist[FAST_CLIST];
     unsigned long long masks[(ZS * ZS + 63) / 64];
 };
@@ -55,46 +55,58 @@ __device__ __forceinline__ uint32_t reject8(us2 c, us2 t, us2 a0, us2 a8, us2 a4
     return as_u32(dark) | as_u32(bright);
 }
 
-// stage 2 for up to 64 queued survivors: corner score = max over the 16 nine-arcs of min(d) / min(-d),
-// minus 1; the pixel is a corner at threshold t  <=>  score >= t, so no separate arc test is needed.
-template <int TS>
-__device__ __forceinline__ bool fast_stage2(const uint8_t *T0, const uint16_t *queue, uint8_t *smap, int cnt,
-                                            int lane, int t_lo, int sms, int *pos_out)
+typedef short ss2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ ss2 pk(int lo, int hi) { return __builtin_bit_cast(ss2, (uint32_t)(lo & 0xFFFF) | ((uint32_t)hi << 16)); }
+
+// stage 2 for up to 128 queued survivors, TWO pixels per lane in the two i16 halves of every register:
+// corner score = max over the 16 nine-arcs of min(d) / min(-d), minus 1 (d = centre - circle pixel).
+// A pixel is a corner at threshold t  <=>  score >= t, so no separate arc test is needed.
+template <int TS, int ZS>
+__device__ __forceinline__ void fast_stage2(const uint8_t *T0, const uint16_t *queue, uint8_t *smap, int cnt,
+                                            int lane, int t_lo, bool *c0, bool *c1, int *pos0, int *pos1)
 {
-    if (lane >= cnt) return false;
-    const int pos = queue[lane];
-    *pos_out = pos;
-    const int y = pos >> 6, x = pos & 63;
-    const uint8_t *p = T0 + (y + 3) * TS + x + 3;
-    const int v = p[0];
-    int d[16];
-    d[0] = v - p[3 * TS];       d[1] = v - p[3 * TS + 1];   d[2] = v - p[2 * TS + 2];   d[3] = v - p[1 * TS + 3];
-    d[4] = v - p[3];            d[5] = v - p[-1 * TS + 3];  d[6] = v - p[-2 * TS + 2];  d[7] = v - p[-3 * TS + 1];
-    d[8] = v - p[-3 * TS];      d[9] = v - p[-3 * TS - 1];  d[10] = v - p[-2 * TS - 2]; d[11] = v - p[-1 * TS - 3];
-    d[12] = v - p[-3];          d[13] = v - p[1 * TS - 3];  d[14] = v - p[2 * TS - 2];  d[15] = v - p[3 * TS - 1];
-    int A = -256, B = 256;
+    *c0 = *c1 = false;
+    if (lane >= cnt) return;
+    const bool two = lane + 64 < cnt;
+    const int pa = queue[lane], pb = two ? queue[lane + 64] : pa;
+    *pos0 = pa; *pos1 = pb;
+    const uint8_t *p = T0 + ((pa >> 6) + 3) * TS + (pa & 63) + 3;
+    const uint8_t *q = T0 + ((pb >> 6) + 3) * TS + (pb & 63) + 3;
+    const ss2 v = pk(p[0], q[0]);
+    ss2 d[16];
+    d[0] = v - pk(p[3 * TS], q[3 * TS]);            d[1] = v - pk(p[3 * TS + 1], q[3 * TS + 1]);
+    d[2] = v - pk(p[2 * TS + 2], q[2 * TS + 2]);    d[3] = v - pk(p[1 * TS + 3], q[1 * TS + 3]);
+    d[4] = v - pk(p[3], q[3]);                      d[5] = v - pk(p[-1 * TS + 3], q[-1 * TS + 3]);
+    d[6] = v - pk(p[-2 * TS + 2], q[-2 * TS + 2]);  d[7] = v - pk(p[-3 * TS + 1], q[-3 * TS + 1]);
+    d[8] = v - pk(p[-3 * TS], q[-3 * TS]);          d[9] = v - pk(p[-3 * TS - 1], q[-3 * TS - 1]);
+    d[10] = v - pk(p[-2 * TS - 2], q[-2 * TS - 2]); d[11] = v - pk(p[-1 * TS - 3], q[-1 * TS - 3]);
+    d[12] = v - pk(p[-3], q[-3]);                   d[13] = v - pk(p[1 * TS - 3], q[1 * TS - 3]);
+    d[14] = v - pk(p[2 * TS - 2], q[2 * TS - 2]);   d[15] = v - pk(p[3 * TS - 1], q[3 * TS - 1]);
+    ss2 A = pk(-256, -256), B = pk(256, 256);
     {
-        int a2[16], a4[16];
+        ss2 a2[16], a4[16];
 #pragma unroll
-        for (int k = 0; k < 16; k++) a2[k] = min(d[k], d[(k + 1) & 15]);
+        for (int k = 0; k < 16; k++) a2[k] = __builtin_elementwise_min(d[k], d[(k + 1) & 15]);
 #pragma unroll
-        for (int k = 0; k < 16; k++) a4[k] = min(a2[k], a2[(k + 2) & 15]);
+        for (int k = 0; k < 16; k++) a4[k] = __builtin_elementwise_min(a2[k], a2[(k + 2) & 15]);
 #pragma unroll
-        for (int k = 0; k < 16; k++) A = max(A, min(min(a4[k], a4[(k + 4) & 15]), d[(k + 8) & 15]));
+        for (int k = 0; k < 16; k++)
+            A = __builtin_elementwise_max(A, __builtin_elementwise_min(__builtin_elementwise_min(a4[k], a4[(k + 4) & 15]), d[(k + 8) & 15]));
     }
     {
-        int b2[16], b4[16];
+        ss2 b2[16], b4[16];
 #pragma unroll
-        for (int k = 0; k < 16; k++) b2[k] = max(d[k], d[(k + 1) & 15]);
+        for (int k = 0; k < 16; k++) b2[k] = __builtin_elementwise_max(d[k], d[(k + 1) & 15]);
 #pragma unroll
-        for (int k = 0; k < 16; k++) b4[k] = max(b2[k], b2[(k + 2) & 15]);
+        for (int k = 0; k < 16; k++) b4[k] = __builtin_elementwise_max(b2[k], b2[(k + 2) & 15]);
 #pragma unroll
-        for (int k = 0; k < 16; k++) B = min(B, max(max(b4[k], b4[(k + 4) & 15]), d[(k + 8) & 15]));
+        for (int k = 0; k < 16; k++)
+            B = __builtin_elementwise_min(B, __builtin_elementwise_max(__builtin_elementwise_max(b4[k], b4[(k + 4) & 15]), d[(k + 8) & 15]));
     }
-    const int score = max(A, -B) - 1;     // <= 254
-    if (score < t_lo) return false;
-    smap[(y + 1) * sms + x + 1] = (uint8_t)score;
-    return true;
+    const ss2 sc = __builtin_elementwise_max(A, -B) - pk(1, 1);   // <= 254
+    const int s0 = sc.x, s1 = sc.y;
+    if (s0 >= t_lo) { smap[((pa >> 6) + 1) * ZS + (pa & 63) + 1] = (uint8_t)s0; *c0 = true; }
+    if (two && s1 >= t_lo) { smap[((pb >> 6) + 1) * ZS + (pb & 63) + 1] = (uint8_t)s1; *c1 = true; }
 }
 
 template <int TS, int TH, int ZS>
@@ -118,9 +130,6 @@ __global__ __launch_bounds__(FAST_THREADS) void k_fast_cells(OrbxPlan plan, Orbx
     const int th = min(iniY + L.hCell + 6, L.maxBY) - iniY;
     const int zw = tw - 6, zh = th - 6;
     if (zw <= 0 || zh <= 0) return;
-    const int t_ini = plan.ini_th, t_min = plan.min_th;
-    const int t_lo = min(t_ini, t_min);
-    const int sms = zw + 2;
     const int npx = zw * zh;
     const uint32_t rcp = (1u << 20) / (uint32_t)zw + 1u;   // idx / zw == (idx * rcp) >> 20 for idx < 4096, zw < 64
 
@@ -145,143 +154,150 @@ __global__ __launch_bounds__(FAST_THREADS) void k_fast_cells(OrbxPlan plan, Orbx
                     *reinterpret_cast<const uint32_t *>(src + (long long)r * L.stride);
         }
     }
-    {   // zero the score map (1-px zero ring = "outside the cell counts as 0")
-        uint32_t *z = reinterpret_cast<uint32_t *>(S.smap);
-        const int nz = (sms * (zh + 2) + 3) >> 2;
-        for (int i = lane; i < nz; i += 64) z[i] = 0;
-    }
-    WSYNC();
     const uint8_t *T0 = S.tile + FAST_PADL + xoff;   // tile origin (cell column 0)
-
-    // ---- stages 1+2.  Stage-1 task = (zone row, dword group): 4 horizontally adjacent pixels ----
-    const int cb = FAST_PADL + xoff + 3;                 // tile byte column of zone column 0
+    const int cb = FAST_PADL + xoff + 3;             // tile byte column of zone column 0
     const int g0 = cb >> 2, ng = ((cb + zw - 1) >> 2) - g0 + 1;
     const uint32_t rcpg = (1u << 16) / (uint32_t)ng + 1u;    // t / ng for t < 1024, ng <= 16
     const int ntask = ng * zh;
-    const us2 tt = as_us2((uint32_t)t_lo * 0x00010001u);
-    int qn = 0, ncl = 0;
-    bool cl_over = false;
-    for (int base = 0; base < ntask; base += 64) {
-        const int t = base + lane;
-        uint32_t f01 = 0, f23 = 0;
-        int zy = 0, zx0 = 0;
-        if (t < ntask) {
-            zy = (int)(((uint32_t)t * rcpg) >> 16);
-            const int g = g0 + (t - zy * ng);
-            zx0 = 4 * g - cb;                                    // zone column of byte 0 of this group
-            const uint32_t *r0 = reinterpret_cast<const uint32_t *>(&S.tile[(zy + 3) * TS]) + g;
-            const uint32_t *rp = reinterpret_cast<const uint32_t *>(&S.tile[(zy + 5) * TS]) + g;
-            const uint32_t *rm = reinterpret_cast<const uint32_t *>(&S.tile[(zy + 1) * TS]) + g;
-            const uint32_t dD = *(reinterpret_cast<const uint32_t *>(&S.tile[(zy + 6) * TS]) + g);   // pixel 0  (0,+3)
-            const uint32_t dU = *(reinterpret_cast<const uint32_t *>(&S.tile[(zy + 0) * TS]) + g);   // pixel 8  (0,-3)
-            const uint32_t cL = r0[-1], cC = r0[0], cR = r0[1];
-            const uint32_t pL = rp[-1], pC = rp[0], pR = rp[1];
-            const uint32_t mL = rm[-1], mC = rm[0], mR = rm[1];
-            const uint32_t d4 = __builtin_amdgcn_alignbyte(cR, cC, 3);    // pixel 4  (+3, 0)
-            const uint32_t d12 = __builtin_amdgcn_alignbyte(cC, cL, 1);   // pixel 12 (-3, 0)
-            const uint32_t d2 = __builtin_amdgcn_alignbyte(pR, pC, 2);    // pixel 2  (+2,+2)
-            const uint32_t d14 = __builtin_amdgcn_alignbyte(pC, pL, 2);   // pixel 14 (-2,+2)
-            const uint32_t d6 = __builtin_amdgcn_alignbyte(mR, mC, 2);    // pixel 6  (+2,-2)
-            const uint32_t d10 = __builtin_amdgcn_alignbyte(mC, mL, 2);   // pixel 10 (-2,-2)
-            f01 = reject8(lo2(cC), tt, lo2(dD), lo2(dU), lo2(d4), lo2(d12), lo2(d2), lo2(d10), lo2(d6), lo2(d14));
-            f23 = reject8(hi2(cC), tt, hi2(dD), hi2(dU), hi2(d4), hi2(d12), hi2(d2), hi2(d10), hi2(d6), hi2(d14));
-        }
-#pragma unroll
-        for (int j = 0; j < 4; j++) {
-            const uint32_t fl = (j < 2 ? f01 : f23) & ((j & 1) ? 0xFFFF0000u : 0x0000FFFFu);
-            const int zx = zx0 + j;
-            const bool pass = fl != 0 && zx >= 0 && zx < zw;
-            const unsigned long long m = __ballot(pass);
-            if (pass) S.queue[qn + __popcll(m & ((1ull << lane) - 1ull))] = (uint16_t)((zy << 6) | zx);
-            qn += __popcll(m);
-            if (qn >= 64) {
-                WSYNC();
-                int pos = 0;
-                const bool corner = fast_stage2<TS>(T0, S.queue, S.smap, 64, lane, t_lo, sms, &pos);
-                const unsigned long long cm = __ballot(corner);
-                const int nc = __popcll(cm);
-                if (ncl + nc <= FAST_CLIST) { if (corner) S.clist[ncl + __popcll(cm & ((1ull << lane) - 1ull))] = (uint16_t)pos; ncl += nc; }
-                else cl_over = true;
-                const int rest = qn - 64;            // move the tail of the queue to the front
-                uint16_t tmpq = 0;
-                if (lane < rest) tmpq = S.queue[64 + lane];
-                WSYNC();
-                if (lane < rest) S.queue[lane] = tmpq;
-                qn = rest;
-                WSYNC();
-            }
-        }
-    }
-    WSYNC();
-    {   // the remaining survivors
-        int pos = 0;
-        const bool corner = fast_stage2<TS>(T0, S.queue, S.smap, qn, lane, t_lo, sms, &pos);
-        const unsigned long long cm = __ballot(corner);
-        const int nc = __popcll(cm);
-        if (ncl + nc <= FAST_CLIST) { if (corner) S.clist[ncl + __popcll(cm & ((1ull << lane) - 1ull))] = (uint16_t)pos; ncl += nc; }
-        else cl_over = true;
-    }
-    WSYNC();
 
-    // ---- stage 3: NMS (strictly greater than all 8 neighbours; outside the cell zone counts as 0).
-    // Items are the listed corners, or every zone pixel if the list overflowed. ----
-    int n_ini = 0, n_min = 0;
-    const int nitem = cl_over ? npx : ncl;
-    const int niter = (nitem + 63) >> 6;
-    for (int it = 0; it < niter; it++) {
-        const int idx = it * 64 + lane;
-        bool ismax = false;
-        int s = 0;
-        if (idx < nitem) {
-            int y, x;
-            if (cl_over) { y = (int)(((uint32_t)idx * rcp) >> 20); x = idx - y * zw; }
-            else { const int pos = S.clist[idx]; y = pos >> 6; x = pos & 63; }
-            const uint8_t *q = &S.smap[(y + 1) * sms + x + 1];
-            s = q[0];
-            if (s > 0)
-                ismax = s > q[-1] && s > q[1] && s > q[-sms - 1] && s > q[-sms] && s > q[-sms + 1] &&
-                        s > q[sms - 1] && s > q[sms] && s > q[sms + 1];
+    // The reference calls FAST at iniThFAST and, only when that cell yields nothing, again at
+    // minThFAST (:811-818).  Same here: the first pass thresholds at iniThFAST; a cell with no NMS
+    // survivor is redone at minThFAST (when that is lower -- a higher one cannot add anything).
+    for (int pass = 0; pass < 2; pass++) {
+        const int t_lo = pass == 0 ? plan.ini_th : plan.min_th;
+        if (pass == 1 && plan.min_th >= plan.ini_th) return;
+        {   // zero the score map (1-px zero ring = "outside the cell counts as 0")
+            uint32_t *z = reinterpret_cast<uint32_t *>(S.smap);
+            const int nz = (ZS * (zh + 2) + 3) >> 2;
+            for (int i = lane; i < nz; i += 64) z[i] = 0;
         }
-        const unsigned long long mm = __ballot(ismax);
-        if (lane == 0) S.masks[it] = mm;
-        n_ini += __popcll(__ballot(ismax && s >= t_ini));
-        n_min += __popcll(__ballot(ismax && s >= t_min));
-    }
-    // reference :811-818: FAST at iniThFAST; only if that yields nothing, FAST at minThFAST
-    const int t_use = n_ini > 0 ? t_ini : t_min;
-    const int total = n_ini > 0 ? n_ini : n_min;
-    if (total == 0) return;
-    int gbase = 0;
-    if (lane == 0) gbase = (int)atomicAdd(&wk.cand_count[f * plan.nlevels + l], (uint32_t)total);
-    gbase = __shfl(gbase, 0);
-    WSYNC();
-    OrbxCand *out = wk.cand + (long long)f * plan.cand_frame + L.cand_off;
-    int written = 0;
-    for (int it = 0; it < niter; it++) {
-        const unsigned long long mm = S.masks[it];
-        if (mm == 0) continue;
-        const int idx = it * 64 + lane;
-        bool emit = false;
-        int y = 0, x = 0, s = 0;
-        if ((mm >> lane) & 1ull) {
-            if (cl_over) { y = (int)(((uint32_t)idx * rcp) >> 20); x = idx - y * zw; }
-            else { const int pos = S.clist[idx]; y = pos >> 6; x = pos & 63; }
-            s = S.smap[(y + 1) * sms + x + 1];
-            emit = s >= t_use;
-        }
-        const unsigned long long em = __ballot(emit);
-        if (emit) {
-            const int o = gbase + written + __popcll(em & ((1ull << lane) - 1ull));
-            if (o < L.cand_cap) {
-                OrbxCand cnd;
-                cnd.xy = (uint32_t)(iniX + 3 + x) | ((uint32_t)(iniY + 3 + y) << 16);
-                cnd.resp = (uint32_t)s;
-                out[o] = cnd;
-            } else {
-                atomicOr(&wk.errflags[f], (uint32_t)ERRF_CAND_OVERFLOW);
+        WSYNC();
+        if (plan.dbg == 1) return;
+
+        // ---- stages 1+2.  Stage-1 task = (zone row, dword group): 4 horizontally adjacent pixels ----
+        const us2 tt = as_us2((uint32_t)t_lo * 0x00010001u);
+        int qn = 0, ncl = 0;
+        bool cl_over = false;
+#define DRAIN(CNT)                                                                                                   \
+    do {                                                                                                             \
+        bool c0_, c1_; int p0_ = 0, p1_ = 0;                                                                         \
+        fast_stage2<TS, ZS>(T0, S.queue, S.smap, (CNT), lane, t_lo, &c0_, &c1_, &p0_, &p1_);                         \
+        const unsigned long long m0_ = __ballot(c0_), m1_ = __ballot(c1_);                                           \
+        const int n0_ = __popcll(m0_), n1_ = __popcll(m1_);                                                          \
+        if (ncl + n0_ + n1_ <= FAST_CLIST) {                                                                         \
+            if (c0_) S.clist[ncl + __popcll(m0_ & ((1ull << lane) - 1ull))] = (uint16_t)p0_;                         \
+            if (c1_) S.clist[ncl + n0_ + __popcll(m1_ & ((1ull << lane) - 1ull))] = (uint16_t)p1_;                   \
+            ncl += n0_ + n1_;                                                                                        \
+        } else cl_over = true;                                                                                       \
+    } while (0)
+        for (int base = 0; base < ntask; base += 64) {
+            const int t = base + lane;
+            uint32_t f01 = 0, f23 = 0;
+            int zy = 0, zx0 = 0;
+            if (t < ntask) {
+                zy = (int)(((uint32_t)t * rcpg) >> 16);
+                const int g = g0 + (t - zy * ng);
+                zx0 = 4 * g - cb;                                    // zone column of byte 0 of this group
+                const uint32_t *r0 = reinterpret_cast<const uint32_t *>(&S.tile[(zy + 3) * TS]) + g;
+                const uint32_t *rp = reinterpret_cast<const uint32_t *>(&S.tile[(zy + 5) * TS]) + g;
+                const uint32_t *rm = reinterpret_cast<const uint32_t *>(&S.tile[(zy + 1) * TS]) + g;
+                const uint32_t dD = *(reinterpret_cast<const uint32_t *>(&S.tile[(zy + 6) * TS]) + g);   // pixel 0  (0,+3)
+                const uint32_t dU = *(reinterpret_cast<const uint32_t *>(&S.tile[(zy + 0) * TS]) + g);   // pixel 8  (0,-3)
+                const uint32_t cL = r0[-1], cC = r0[0], cR = r0[1];
+                const uint32_t pL = rp[-1], pC = rp[0], pR = rp[1];
+                const uint32_t mL = rm[-1], mC = rm[0], mR = rm[1];
+                const uint32_t d4 = __builtin_amdgcn_alignbyte(cR, cC, 3);    // pixel 4  (+3, 0)
+                const uint32_t d12 = __builtin_amdgcn_alignbyte(cC, cL, 1);   // pixel 12 (-3, 0)
+                const uint32_t d2 = __builtin_amdgcn_alignbyte(pR, pC, 2);    // pixel 2  (+2,+2)
+                const uint32_t d14 = __builtin_amdgcn_alignbyte(pC, pL, 2);   // pixel 14 (-2,+2)
+                const uint32_t d6 = __builtin_amdgcn_alignbyte(mR, mC, 2);    // pixel 6  (+2,-2)
+                const uint32_t d10 = __builtin_amdgcn_alignbyte(mC, mL, 2);   // pixel 10 (-2,-2)
+                f01 = reject8(lo2(cC), tt, lo2(dD), lo2(dU), lo2(d4), lo2(d12), lo2(d2), lo2(d10), lo2(d6), lo2(d14));
+                f23 = reject8(hi2(cC), tt, hi2(dD), hi2(dU), hi2(d4), hi2(d12), hi2(d2), hi2(d10), hi2(d6), hi2(d14));
+            }
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const uint32_t fl = (j < 2 ? f01 : f23) & ((j & 1) ? 0xFFFF0000u : 0x0000FFFFu);
+                const int zx = zx0 + j;
+                const bool ok = fl != 0 && zx >= 0 && zx < zw;
+                const unsigned long long m = __ballot(ok);
+                if (ok) S.queue[qn + __popcll(m & ((1ull << lane) - 1ull))] = (uint16_t)((zy << 6) | zx);
+                qn += __popcll(m);
+                if (qn >= 128 && plan.dbg == 2) qn -= 128;
+                if (qn >= 128) {
+                    WSYNC();
+                    DRAIN(128);
+                    const int rest = qn - 128;            // move the tail of the queue to the front
+                    uint16_t tmpq = 0;
+                    if (lane < rest) tmpq = S.queue[128 + lane];
+                    WSYNC();
+                    if (lane < rest) S.queue[lane] = tmpq;
+                    qn = rest;
+                    WSYNC();
+                }
             }
         }
-        written += __popcll(em);
+        WSYNC();
+        if (plan.dbg == 2) { if (qn == 12345) wk.errflags[f] = 1; return; }
+        DRAIN(qn);   // the remaining survivors (qn < 128)
+#undef DRAIN
+        WSYNC();
+        if (plan.dbg == 3) { if (ncl == 12345) wk.errflags[f] = 1; return; }
+
+        // ---- stage 3: NMS (strictly greater than all 8 neighbours; outside the cell zone counts as 0).
+        // Items are the listed corners, or every zone pixel if the list overflowed. ----
+        int total = 0;
+        const int nitem = cl_over ? npx : ncl;
+        const int niter = (nitem + 63) >> 6;
+        for (int it = 0; it < niter; it++) {
+            const int idx = it * 64 + lane;
+            bool ismax = false;
+            if (idx < nitem) {
+                int y, x;
+                if (cl_over) { y = (int)(((uint32_t)idx * rcp) >> 20); x = idx - y * zw; }
+                else { const int pos = S.clist[idx]; y = pos >> 6; x = pos & 63; }
+                const uint8_t *q = &S.smap[(y + 1) * ZS + x + 1];
+                const int s = q[0];
+                if (s > 0)
+                    ismax = s > q[-1] && s > q[1] && s > q[-ZS - 1] && s > q[-ZS] && s > q[-ZS + 1] &&
+                            s > q[ZS - 1] && s > q[ZS] && s > q[ZS + 1];
+            }
+            const unsigned long long mm = __ballot(ismax);
+            if (lane == 0) S.masks[it] = mm;
+            total += __popcll(mm);
+        }
+        if (plan.dbg == 5) { if (total == 12345) wk.errflags[f] = 1; return; }
+        if (total == 0) continue;   // nothing at this threshold: fall back to the lower one
+        if (plan.dbg == 6) { if (total == 12345) wk.errflags[f] = 1; return; }
+
+        int gbase = 0;
+        if (lane == 0 && plan.dbg != 7) gbase = (int)atomicAdd(&ORBX_CNT(wk, plan, f, l), (uint32_t)total);
+        if (plan.dbg == 7) gbase = (c * 7) % (L.cand_cap - 64);
+        gbase = __shfl(gbase, 0);
+        WSYNC();
+        OrbxCand *out = wk.cand + (long long)f * plan.cand_frame + L.cand_off;
+        int written = 0;
+        for (int it = 0; it < niter; it++) {
+            const unsigned long long mm = S.masks[it];
+            if (mm == 0) continue;
+            const int idx = it * 64 + lane;
+            if ((mm >> lane) & 1ull) {
+                int y, x;
+                if (cl_over) { y = (int)(((uint32_t)idx * rcp) >> 20); x = idx - y * zw; }
+                else { const int pos = S.clist[idx]; y = pos >> 6; x = pos & 63; }
+                const int o = gbase + written + __popcll(mm & ((1ull << lane) - 1ull));
+                if (o < L.cand_cap) {
+                    OrbxCand cnd;
+                    cnd.xy = (uint32_t)(iniX + 3 + x) | ((uint32_t)(iniY + 3 + y) << 16);
+                    cnd.resp = (uint32_t)S.smap[(y + 1) * ZS + x + 1];
+                    out[o] = cnd;
+                } else {
+                    atomicOr(&wk.errflags[f], (uint32_t)ERRF_CAND_OVERFLOW);
+                }
+            }
+            written += __popcll(mm);
+        }
+        return;
     }
 }
 

@@ -14,6 +14,9 @@
 #define FAST_ZONE_MAX 60
 #define FAST_THREADS 256
 
+#define ORBX_CNT_STRIDE 32
+#define ORBX_CNT(wk, plan, f, l) ((wk).cand_count[((f) * (plan).nlevels + (l)) * ORBX_CNT_STRIDE])
+
 #define OCT_THREADS 512
 #define OCT_ID_MASK 0x3FFFFFFFu
 
@@ -57,6 +60,7 @@ struct OrbxPlan {
     int ncells;                   // cells per frame over all levels
     int blur_mode;
     int out_cap;                  // per-frame output capacity
+    int dbg;                      // ORBX_DBG_STAGE ablation switch (0 = normal), timing experiments only
     long long cand_frame;         // candidates per frame (elements)
     long long list_frame;         // sel entries per frame
     long long arena_frame;        // arena nodes per frame
@@ -65,7 +69,8 @@ struct OrbxPlan {
 
 struct OrbxWork {                 // device workspace pointers (per handle)
     OrbxCand *cand;               // [B][cand_frame]
-    uint32_t *cand_count;         // [B][L]
+    uint32_t *cand_count;         // [B][L] counters, ORBX_CNT_STRIDE dwords apart (one 128-B line each:
+                                  // atomics that share a line serialise in the L2 channel)
     uint32_t *owner;              // [B][cand_frame]  quadtree: key -> node id (| quadrant << 30)
     OrbxNode *arena;              // [B][arena_frame]
     OrbxCand *sel;                // [B][list_frame]  selected keypoints per level, list order

@@ -83,7 +83,7 @@ __global__ __launch_bounds__(OCT_THREADS) void k_octree(OrbxPlan plan, OrbxWork 
     uint32_t *owner = wk.owner + (long long)f * plan.cand_frame + L.cand_off;
     OrbxNode *arena = wk.arena + (long long)f * plan.arena_frame + L.arena_off;
     OrbxCand *sel = wk.sel + (long long)f * plan.list_frame + L.list_off;
-    const int n = (int)min(wk.cand_count[f * plan.nlevels + l], (uint32_t)L.cand_cap);
+    const int n = (int)min(ORBX_CNT(wk, plan, f, l), (uint32_t)L.cand_cap);
 
     if (n == 0 || L.nIni <= 0) {
         if (tid == 0) wk.nk[f * plan.nlevels + l] = 0;
