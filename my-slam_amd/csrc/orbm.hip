@@ -1,8 +1,9 @@
 // orbm.hip -- gfx950 Hamming matcher primitives + their C ABI (include/orbm.h).
 // Reference: src/ORBmatcher.cc of WChen09/My-SLAM (DescriptorDistance :1647-1663, best/second-best
 // loops :201-232 and siblings, ComputeThreeMaxima :1601-1642).  Integer/bitwise only: v_xor_b32 +
-// v_bcnt_u32_b32 (popcount with accumulate); the train set is staged through LDS in 8 KiB tiles and
-// read back as wave-uniform broadcasts, so the kernel is VALU-bound, not HBM-bound.
+// v_bcnt_u32_b32 (popcount with accumulate); in the dense kernel the train descriptor of a step is
+// wave-uniform and comes through the scalar cache, so the kernel is VALU-bound, not HBM-bound
+// (16 M pairs touch 256 KB).
 #include <algorithm>
 #include <cmath>
 #include <cstdarg>
@@ -15,7 +16,6 @@
 #include "../../include/orbm.h"
 
 #define M_THREADS 256
-#define M_TILE 256
 
 static thread_local std::string g_merr;
 static int mfail(int code, const char *fmt, ...)
@@ -48,42 +48,66 @@ __device__ __forceinline__ int hamming256(const uint4 &a0, const uint4 &a1, cons
     return d;
 }
 
-// ---- dense best/second-best: one query per thread, train tiles broadcast from LDS ----
+// ---- dense best/second-best: one query per thread (8 VGPRs); the train descriptor of a step is
+// wave-uniform, so it arrives through the scalar cache (s_load_dwordx8) and feeds v_xor_b32 as an
+// SGPR operand: no LDS, no barrier.  gridDim.z splits the train range; every split writes a partial
+// (best key, second key) with key = distance << 22 | train index, so "strictly smaller wins, first
+// index wins a tie, a tie with the best becomes the second best" (src/ORBmatcher.cc:214-223) is
+// min / median on keys and partials merge exactly (k_merge_best2 / k_accept_rot). ----
+#define M_KEY_NONE ((256u << 22) | 0x3FFFFFu)
+__device__ __forceinline__ uint32_t med3u(uint32_t a, uint32_t b, uint32_t c) { return max(min(a, b), min(max(a, b), c)); }
+
 __global__ __launch_bounds__(M_THREADS) void k_best2_dense(
     const uint8_t *__restrict__ q, const int32_t *__restrict__ nqv, int nq_fixed,
     const uint8_t *__restrict__ t, const int32_t *__restrict__ ntv, int nt_fixed,
-    long long qstride, long long tstride, int out_stride,
-    int32_t *__restrict__ best_idx, int32_t *__restrict__ best_d, int32_t *__restrict__ second_d)
+    long long qstride, long long tstride, int out_stride, uint2 *__restrict__ part)
 {
-    __shared__ uint4 tile[M_TILE * 2];
     const int b = blockIdx.y, tid = threadIdx.x;
     const int nq = nqv ? nqv[b] : nq_fixed;
     const int nt = ntv ? ntv[b] : nt_fixed;
     if ((int)(blockIdx.x * M_THREADS) >= nq) return;
     const int qi = blockIdx.x * M_THREADS + tid;
+    const int S = gridDim.z, chunk = (nt + S - 1) / S;
+    const int j0 = blockIdx.z * chunk, j1 = min(nt, j0 + chunk);
     const uint4 *Q = reinterpret_cast<const uint4 *>(q + (long long)b * qstride);
     const uint4 *T = reinterpret_cast<const uint4 *>(t + (long long)b * tstride);
     uint4 q0 = make_uint4(0, 0, 0, 0), q1 = q0;
     if (qi < nq) { q0 = Q[2 * qi]; q1 = Q[2 * qi + 1]; }
-    int bd = 256, sd = 256, bi = -1;
-    for (int t0 = 0; t0 < nt; t0 += M_TILE) {
-        __syncthreads();
-        const int cnt = min(M_TILE, nt - t0);
-        for (int i = tid; i < cnt * 2; i += M_THREADS) tile[i] = T[2 * t0 + i];
-        __syncthreads();
-        if (qi < nq) {
+    uint32_t bk = M_KEY_NONE, sk = M_KEY_NONE;
 #pragma unroll 4
-            for (int j = 0; j < cnt; j++) {
-                const int d = hamming256(q0, q1, tile[2 * j], tile[2 * j + 1]);
-                if (d < bd) { sd = bd; bd = d; bi = t0 + j; }        // :214-219
-                else if (d < sd) { sd = d; }                        // :220-223
-            }
-        }
+    for (int j = j0; j < j1; j++) {
+        const uint4 a0 = T[2 * j], a1 = T[2 * j + 1];      // uniform address: scalar loads
+        const uint32_t key = ((uint32_t)hamming256(q0, q1, a0, a1) << 22) | (uint32_t)j;
+        sk = med3u(bk, sk, key);                            // second smallest of {bk <= sk, key}
+        bk = min(bk, key);
     }
-    if (qi < nq) {
-        const long long o = (long long)b * out_stride + qi;
-        best_idx[o] = bi; best_d[o] = bd; second_d[o] = sd;
+    if (qi < nq) part[((long long)blockIdx.z * gridDim.y + b) * out_stride + qi] = make_uint2(bk, sk);
+}
+
+// merge the train-range partials of one query: the two smallest keys of the union
+__device__ __forceinline__ void merge_partials(const uint2 *__restrict__ part, int S, long long stride_z, long long o,
+                                               int &bi, int &bd, int &sd)
+{
+    uint32_t bk = M_KEY_NONE, sk = M_KEY_NONE;
+    for (int z = 0; z < S; z++) {
+        const uint2 p = part[(long long)z * stride_z + o];
+        sk = med3u(bk, sk, p.x); bk = min(bk, p.x);
+        sk = med3u(bk, sk, p.y); bk = min(bk, p.y);
     }
+    bd = (int)(bk >> 22);
+    sd = (int)(sk >> 22);
+    bi = bd < 256 ? (int)(bk & 0x3FFFFFu) : -1;
+}
+
+__global__ __launch_bounds__(M_THREADS) void k_merge_best2(const uint2 *__restrict__ part, int S, int nq,
+                                                          int32_t *__restrict__ best_idx, int32_t *__restrict__ best_d,
+                                                          int32_t *__restrict__ second_d)
+{
+    const int i = blockIdx.x * M_THREADS + threadIdx.x;
+    if (i >= nq) return;
+    int bi, bd, sd;
+    merge_partials(part, S, nq, i, bi, bd, sd);
+    best_idx[i] = bi; best_d[i] = bd; second_d[i] = sd;
 }
 
 // ---- CSR best/second-best: one wave per query ----
@@ -179,9 +203,9 @@ __device__ __forceinline__ void three_maxima(const int *histo, int L, int &ind1,
 
 __global__ __launch_bounds__(M_THREADS) void k_accept_rot(
     const int32_t *__restrict__ nqv, const orbx_keypoint *__restrict__ kq, const orbx_keypoint *__restrict__ kt,
-    int cap, const int32_t *__restrict__ best_idx, const int32_t *__restrict__ best_d,
-    const int32_t *__restrict__ second_d, int th, float nnratio, int check_ori,
-    int32_t *__restrict__ match12, int32_t *__restrict__ nmatches)
+    int cap, const uint2 *__restrict__ part, int S, int th, float nnratio, int check_ori,
+    int32_t *__restrict__ match12, int32_t *__restrict__ nmatches,
+    int32_t *__restrict__ best_idx, int32_t *__restrict__ best_d, int32_t *__restrict__ second_d)
 {
     __shared__ int hist[32];
     __shared__ int s_ind[3];
@@ -189,13 +213,16 @@ __global__ __launch_bounds__(M_THREADS) void k_accept_rot(
     const int b = blockIdx.x, tid = threadIdx.x;
     const int nq = nqv[b];
     const long long base = (long long)b * cap;
+    const long long stride_z = (long long)gridDim.x * cap;
     if (tid < 32) hist[tid] = 0;
     if (tid == 0) s_count = 0;
     __syncthreads();
     for (int i = tid; i < nq; i += M_THREADS) {
-        const int bd = best_d[base + i], sd = second_d[base + i];
+        int bi, bd, sd;
+        merge_partials(part, S, stride_z, base + i, bi, bd, sd);
+        if (best_idx) { best_idx[base + i] = bi; best_d[base + i] = bd; second_d[base + i] = sd; }
         int m = -1;
-        if (bd <= th && (float)bd < __fmul_rn(nnratio, (float)sd)) m = best_idx[base + i];
+        if (bd <= th && (float)bd < __fmul_rn(nnratio, (float)sd)) m = bi;     // :228-232
         match12[base + i] = m;
         if (m >= 0 && check_ori) atomicAdd(&hist[rot_bin(kq[base + i].angle, kt[base + m].angle)], 1);
     }
@@ -229,8 +256,7 @@ struct orbm_matcher {
     hipStream_t stream = nullptr;
     uint8_t *d_q = nullptr, *d_t = nullptr;
     int32_t *d_off = nullptr, *d_idx = nullptr, *d_out = nullptr;   // d_out: max(3*max_q, max_pairs) ints
-    int32_t *d_bi = nullptr, *d_bd = nullptr, *d_sd = nullptr;       // batch scratch (lazy)
-    size_t batch_elems = 0;
+    uint2 *d_part = nullptr; size_t part_elems = 0;                  // train-split partials (lazy)
 };
 
 extern "C" int orbm_distance(const uint8_t a[32], const uint8_t b[32])
@@ -250,7 +276,7 @@ extern "C" void orbm_destroy(orbm_matcher *m)
     if (!m) return;
     (void)hipSetDevice(m->device);
     (void)hipFree(m->d_q); (void)hipFree(m->d_t); (void)hipFree(m->d_off); (void)hipFree(m->d_idx);
-    (void)hipFree(m->d_out); (void)hipFree(m->d_bi); (void)hipFree(m->d_bd); (void)hipFree(m->d_sd);
+    (void)hipFree(m->d_out); (void)hipFree(m->d_part);
     if (m->stream) (void)hipStreamDestroy(m->stream);
     delete m;
 }
@@ -293,6 +319,26 @@ static int check_csr(const int32_t *off, const int32_t *idx, int nq, int nt, int
     return ORBX_OK;
 }
 
+// train-range splits so that the launch has >= ~4 waves per SIMD (1024 SIMDs); <= 64
+static int pick_splits(int nq_cap, int nbatch, int nt_hint)
+{
+    const long long waves = (long long)nbatch * ((nq_cap + M_THREADS - 1) / M_THREADS) * (M_THREADS / 64);
+    int S = (int)((4096 + waves - 1) / waves);
+    S = std::max(1, std::min(S, 64));
+    while (S > 1 && nt_hint / S < 16) S--;       // keep >= 16 train descriptors per split
+    return S;
+}
+static int ensure_partials(orbm_matcher *m, size_t need)
+{
+    if (need <= m->part_elems) return ORBX_OK;
+    MHIPCHK(hipDeviceSynchronize());
+    (void)hipFree(m->d_part);
+    m->d_part = nullptr; m->part_elems = 0;
+    MHIPCHK(hipMalloc((void **)&m->d_part, need * sizeof(uint2)));
+    m->part_elems = need;
+    return ORBX_OK;
+}
+
 extern "C" int orbm_best2(orbm_matcher *m, const uint8_t *q, int nq, const uint8_t *t, int nt,
                           const int32_t *cand_off, const int32_t *cand_idx,
                           int32_t *best_idx, int32_t *best_d, int32_t *second_d)
@@ -314,8 +360,12 @@ extern "C" int orbm_best2(orbm_matcher *m, const uint8_t *q, int nq, const uint8
         if (total > 0) MHIPCHK(hipMemcpyAsync(m->d_idx, cand_idx, (size_t)total * 4, hipMemcpyHostToDevice, s));
         hipLaunchKernelGGL(k_best2_csr, dim3((nq + 3) / 4), dim3(M_THREADS), 0, s, m->d_q, nq, m->d_t, m->d_off, m->d_idx, o_bi, o_bd, o_sd);
     } else {
-        hipLaunchKernelGGL(k_best2_dense, dim3((nq + M_THREADS - 1) / M_THREADS, 1), dim3(M_THREADS), 0, s,
-                           m->d_q, (const int32_t *)nullptr, nq, m->d_t, (const int32_t *)nullptr, nt, 0LL, 0LL, 0, o_bi, o_bd, o_sd);
+        const int S = pick_splits(nq, 1, nt);
+        int rc = ensure_partials(m, (size_t)S * nq);
+        if (rc != ORBX_OK) return rc;
+        hipLaunchKernelGGL(k_best2_dense, dim3((nq + M_THREADS - 1) / M_THREADS, 1, S), dim3(M_THREADS), 0, s,
+                           m->d_q, (const int32_t *)nullptr, nq, m->d_t, (const int32_t *)nullptr, nt, 0LL, 0LL, nq, m->d_part);
+        hipLaunchKernelGGL(k_merge_best2, dim3((nq + M_THREADS - 1) / M_THREADS), dim3(M_THREADS), 0, s, m->d_part, S, nq, o_bi, o_bd, o_sd);
     }
     MHIPCHK(hipGetLastError());
     MHIPCHK(hipMemcpyAsync(best_idx, o_bi, (size_t)nq * 4, hipMemcpyDeviceToHost, s));
@@ -360,45 +410,67 @@ extern "C" int orbm_distances(orbm_matcher *m, const uint8_t *q, int nq, const u
     return ORBX_OK;
 }
 
-extern "C" int orbm_best2_batch_device(orbm_matcher *m, const uint8_t *d_q, const int32_t *d_nq,
-                                       const uint8_t *d_t, const int32_t *d_nt, int cap, int nbatch,
-                                       int32_t *d_best_idx, int32_t *d_best_d, int32_t *d_second_d, void *hip_stream)
+static int launch_dense_batch(orbm_matcher *m, const uint8_t *d_q, const int32_t *d_nq, const uint8_t *d_t,
+                              const int32_t *d_nt, int cap, int nbatch, hipStream_t s, int *S_out)
 {
-    if (!m) return mfail(ORBX_E_INVALID, "NULL handle");
-    if (!d_q || !d_nq || !d_t || !d_nt || !d_best_idx || !d_best_d || !d_second_d) return mfail(ORBX_E_INVALID, "NULL device pointer");
-    if (cap < 1 || nbatch < 1) return mfail(ORBX_E_INVALID, "cap=%d nbatch=%d", cap, nbatch);
-    MHIPCHK(hipSetDevice(m->device));
-    hipStream_t s = hip_stream ? (hipStream_t)hip_stream : m->stream;
-    hipLaunchKernelGGL(k_best2_dense, dim3((cap + M_THREADS - 1) / M_THREADS, nbatch), dim3(M_THREADS), 0, s,
-                       d_q, d_nq, 0, d_t, d_nt, 0, (long long)cap * 32, (long long)cap * 32, cap,
-                       d_best_idx, d_best_d, d_second_d);
+    const int S = pick_splits(cap, nbatch, cap);
+    int rc = ensure_partials(m, (size_t)S * nbatch * cap);
+    if (rc != ORBX_OK) return rc;
+    hipLaunchKernelGGL(k_best2_dense, dim3((cap + M_THREADS - 1) / M_THREADS, nbatch, S), dim3(M_THREADS), 0, s,
+                       d_q, d_nq, 0, d_t, d_nt, 0, (long long)cap * 32, (long long)cap * 32, cap, m->d_part);
     MHIPCHK(hipGetLastError());
+    *S_out = S;
     return ORBX_OK;
 }
 
+// all-ones acceptance (th = 256 never rejects a found match; nnratio huge) is not what best2 wants:
+// k_accept_rot also exports the merged (best_idx, best_d, second_d) when given the arrays.
 extern "C" int orbm_match_batch_device(orbm_matcher *m, const uint8_t *d_q, const orbx_keypoint *d_kq,
                                        const int32_t *d_nq, const uint8_t *d_t, const orbx_keypoint *d_kt,
                                        const int32_t *d_nt, int cap, int nbatch, int th, float nnratio,
                                        int check_orientation, int32_t *d_match12, int32_t *d_nmatches, void *hip_stream)
 {
     if (!m) return mfail(ORBX_E_INVALID, "NULL handle");
-    if (!d_kq || !d_kt || !d_match12 || !d_nmatches) return mfail(ORBX_E_INVALID, "NULL device pointer");
+    if (!d_q || !d_nq || !d_t || !d_nt || !d_kq || !d_kt || !d_match12 || !d_nmatches) return mfail(ORBX_E_INVALID, "NULL device pointer");
+    if (cap < 1 || nbatch < 1 || cap > 0x3FFFFF) return mfail(ORBX_E_INVALID, "cap=%d nbatch=%d", cap, nbatch);
     MHIPCHK(hipSetDevice(m->device));
-    const size_t need = (size_t)cap * nbatch;
-    if (need > m->batch_elems) {
-        MHIPCHK(hipDeviceSynchronize());
-        (void)hipFree(m->d_bi); (void)hipFree(m->d_bd); (void)hipFree(m->d_sd);
-        m->d_bi = m->d_bd = m->d_sd = nullptr; m->batch_elems = 0;
-        MHIPCHK(hipMalloc((void **)&m->d_bi, need * 4));
-        MHIPCHK(hipMalloc((void **)&m->d_bd, need * 4));
-        MHIPCHK(hipMalloc((void **)&m->d_sd, need * 4));
-        m->batch_elems = need;
-    }
-    int rc = orbm_best2_batch_device(m, d_q, d_nq, d_t, d_nt, cap, nbatch, m->d_bi, m->d_bd, m->d_sd, hip_stream);
-    if (rc != ORBX_OK) return rc;
     hipStream_t s = hip_stream ? (hipStream_t)hip_stream : m->stream;
-    hipLaunchKernelGGL(k_accept_rot, dim3(nbatch), dim3(M_THREADS), 0, s, d_nq, d_kq, d_kt, cap, m->d_bi, m->d_bd, m->d_sd,
-                       th, nnratio, check_orientation, d_match12, d_nmatches);
+    int S = 1;
+    int rc = launch_dense_batch(m, d_q, d_nq, d_t, d_nt, cap, nbatch, s, &S);
+    if (rc != ORBX_OK) return rc;
+    hipLaunchKernelGGL(k_accept_rot, dim3(nbatch), dim3(M_THREADS), 0, s, d_nq, d_kq, d_kt, cap, m->d_part, S,
+                       th, nnratio, check_orientation, d_match12, d_nmatches,
+                       (int32_t *)nullptr, (int32_t *)nullptr, (int32_t *)nullptr);
+    MHIPCHK(hipGetLastError());
+    return ORBX_OK;
+}
+
+__global__ __launch_bounds__(M_THREADS) void k_merge_batch(const uint2 *__restrict__ part, int S, const int32_t *__restrict__ nqv,
+                                                          int cap, int32_t *__restrict__ best_idx,
+                                                          int32_t *__restrict__ best_d, int32_t *__restrict__ second_d)
+{
+    const int b = blockIdx.y, i = blockIdx.x * M_THREADS + threadIdx.x;
+    if (i >= cap) return;
+    const long long o = (long long)b * cap + i;
+    int bi = -1, bd = 256, sd = 256;
+    if (i < nqv[b]) merge_partials(part, S, (long long)gridDim.y * cap, o, bi, bd, sd);
+    best_idx[o] = bi; best_d[o] = bd; second_d[o] = sd;
+}
+
+extern "C" int orbm_best2_batch_device(orbm_matcher *m, const uint8_t *d_q, const int32_t *d_nq,
+                                       const uint8_t *d_t, const int32_t *d_nt, int cap, int nbatch,
+                                       int32_t *d_best_idx, int32_t *d_best_d, int32_t *d_second_d, void *hip_stream)
+{
+    if (!m) return mfail(ORBX_E_INVALID, "NULL handle");
+    if (!d_q || !d_nq || !d_t || !d_nt || !d_best_idx || !d_best_d || !d_second_d) return mfail(ORBX_E_INVALID, "NULL device pointer");
+    if (cap < 1 || nbatch < 1 || cap > 0x3FFFFF) return mfail(ORBX_E_INVALID, "cap=%d nbatch=%d", cap, nbatch);
+    MHIPCHK(hipSetDevice(m->device));
+    hipStream_t s = hip_stream ? (hipStream_t)hip_stream : m->stream;
+    int S = 1;
+    int rc = launch_dense_batch(m, d_q, d_nq, d_t, d_nt, cap, nbatch, s, &S);
+    if (rc != ORBX_OK) return rc;
+    hipLaunchKernelGGL(k_merge_batch, dim3((cap + M_THREADS - 1) / M_THREADS, nbatch), dim3(M_THREADS), 0, s,
+                       m->d_part, S, d_nq, cap, d_best_idx, d_best_d, d_second_d);
     MHIPCHK(hipGetLastError());
     return ORBX_OK;
 }
