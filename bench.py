@@ -93,6 +93,7 @@ def main():
     ap.add_argument("--height", type=int, default=480)
     ap.add_argument("--nfeatures", type=int, default=1000)
     ap.add_argument("--batch", type=int, default=64, help="frames per GPU per step")
+    ap.add_argument("--subbatches", type=int, default=0, help="0 = library default")
     ap.add_argument("--no-match", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-budget", type=float, default=12.0)
@@ -120,6 +121,8 @@ def main():
     frames_np = synth.stream(4 + rank, W, H, B)
     frames = torch.from_numpy(frames_np).cuda()
     ex = pkg.ORBextractor(NF, 1.2, 8, 20, 7, device=local, max_width=W, max_height=H, max_batch=B)
+    if args.subbatches:
+        ex.set_subbatches(args.subbatches)
     cap = ex.cap
     kps = torch.zeros((B, cap, 7), dtype=torch.float32, device="cuda")
     desc = torch.zeros((B, cap, 32), dtype=torch.uint8, device="cuda")

@@ -24,6 +24,7 @@ assert KP_DTYPE.itemsize == 28
 ORBX_OK = 0
 ORBX_E_INVALID, ORBX_E_CAPACITY, ORBX_E_SHAPE, ORBX_E_HIP, ORBX_E_CAND_OVERFLOW, ORBX_E_TREE_OVERFLOW = -1, -2, -3, -4, -5, -6
 ORBX_OPT_BLUR_ROUNDING = 1
+ORBX_OPT_SUBBATCHES = 2
 
 
 class OrbxError(RuntimeError):
@@ -162,6 +163,9 @@ class ORBextractor:
 
     def set_blur_rounding(self, mode):
         _chk(self.L.orbx_set_option(self.h, ORBX_OPT_BLUR_ROUNDING, mode))
+
+    def set_subbatches(self, n):
+        _chk(self.L.orbx_set_option(self.h, ORBX_OPT_SUBBATCHES, n))
 
     def set_profiling(self, on):
         _chk(self.L.orbx_set_profiling(self.h, int(on)))

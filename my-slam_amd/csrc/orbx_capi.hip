@@ -38,6 +38,7 @@ static inline int cv_floor(double v) { int i = (int)v; return i - (v < i); }
 static inline int cv_ceil(double v) { int i = (int)v; return i + (v > i); }
 static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
+#define ORBX_MAX_SUB 4
 struct orbx_extractor {
     int nfeatures = 0; float scale_factor = 0; int nlevels = 0, ini_th = 0, min_th = 0, device = 0;
     int max_w = 0, max_h = 0, max_batch = 0;
@@ -46,6 +47,7 @@ struct orbx_extractor {
     int umax[16]; int gauss_k[7];
     int blur_mode = 0;
     hipStream_t stream = nullptr;
+    hipStream_t aux[ORBX_MAX_SUB - 1] = {}; hipEvent_t ev_fork = nullptr, ev_join[ORBX_MAX_SUB - 1] = {}; int nsub = 1;
     // current plan
     int cur_w = 0, cur_h = 0; int last_batch = 0;
     const uint8_t *last_input = nullptr; int last_in_stride = 0; long long last_in_frame = 0;
@@ -183,6 +185,9 @@ static void free_all(orbx_extractor *h)
     hipFree(h->d_kps); hipFree(h->d_desc); hipFree(h->d_counts); hipFree(h->d_status);
     hipHostFree(h->h_kps); hipHostFree(h->h_desc); hipHostFree(h->h_counts); hipHostFree(h->h_status);
     for (auto &e : h->ev) if (e) hipEventDestroy(e);
+    for (auto &e : h->ev_join) if (e) hipEventDestroy(e);
+    if (h->ev_fork) hipEventDestroy(h->ev_fork);
+    for (auto &a : h->aux) if (a) hipStreamDestroy(a);
     if (h->stream) hipStreamDestroy(h->stream);
     delete h;
 }
@@ -259,6 +264,9 @@ extern "C" int orbx_create(orbx_extractor **out, int nfeatures, float scale_fact
     }
     if (hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess) { free_all(h); return fail(ORBX_E_HIP, "hipStreamCreate failed"); }
     for (auto &e : h->ev) if (hipEventCreate(&e) != hipSuccess) { free_all(h); return fail(ORBX_E_HIP, "hipEventCreate failed"); }
+    for (auto &a : h->aux) if (hipStreamCreateWithFlags(&a, hipStreamNonBlocking) != hipSuccess) { free_all(h); return fail(ORBX_E_HIP, "hipStreamCreate failed"); }
+    for (auto &e : h->ev_join) if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) { free_all(h); return fail(ORBX_E_HIP, "hipEventCreate failed"); }
+    if (hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming) != hipSuccess) { free_all(h); return fail(ORBX_E_HIP, "hipEventCreate failed"); }
     if (orbx_upload_constants(h->umax, h->gauss_k) != 0) { free_all(h); return fail(ORBX_E_HIP, "constant upload failed"); }
     *out = h;
     return ORBX_OK;
@@ -270,6 +278,7 @@ extern "C" int orbx_set_option(orbx_extractor *h, int option, int value)
 {
     if (!h) return fail(ORBX_E_INVALID, "NULL handle");
     if (option == ORBX_OPT_BLUR_ROUNDING && (value == 0 || value == 1)) { h->blur_mode = value; h->plan.blur_mode = value; return ORBX_OK; }
+    if (option == ORBX_OPT_SUBBATCHES && value >= 1 && value <= ORBX_MAX_SUB) { h->nsub = value; return ORBX_OK; }
     return fail(ORBX_E_INVALID, "unknown option %d=%d", option, value);
 }
 extern "C" int orbx_get_levels(const orbx_extractor *h) { return h ? h->nlevels : 0; }
@@ -362,20 +371,50 @@ static int enqueue(orbx_extractor *h, const uint8_t *d_images, int nframes, int 
     const bool prof = h->profiling != 0;
     HIPCHK(hipMemsetAsync(h->work.cand_count, 0, (size_t)nframes * h->nlevels * ORBX_CNT_STRIDE * sizeof(uint32_t), s));
     HIPCHK(hipMemsetAsync(h->work.errflags, 0, (size_t)nframes * sizeof(uint32_t), s));
-    if (prof) HIPCHK(hipEventRecord(h->ev[0], s));
-    for (int l = 1; l < h->nlevels; l++) {
-        const uint8_t *src_end = nullptr;   // level 0 in caller memory has no slack behind its last byte
-        if (l == 1 && d_images != h->d_input)
-            src_end = d_images + (long long)(nframes - 1) * frame_stride + (long long)(H - 1) * row_stride + W;
-        orbx_launch_resize(P.lv[l - 1], P.lv[l], h->tabs[l], h->area2[l], nframes, src_end, s);
+    const uint8_t *src_end = nullptr;   // level 0 in caller memory has no slack behind its last byte
+    if (d_images != h->d_input)
+        src_end = d_images + (long long)(nframes - 1) * frame_stride + (long long)(H - 1) * row_stride + W;
+
+    // Sub-batches on separate streams: the quadtree and the small pyramid levels are latency-bound
+    // (few, long workgroups), so one half-batch's latency-bound kernels run beside the other half's
+    // VALU-bound ones.  Frames are independent, so a sub-batch is only a pointer offset.
+    int nsub = (prof || nframes < 16) ? 1 : std::min(h->nsub, ORBX_MAX_SUB);
+    hipStream_t st[ORBX_MAX_SUB];
+    OrbxPlan sp[ORBX_MAX_SUB];
+    OrbxWork sw[ORBX_MAX_SUB];
+    int f0[ORBX_MAX_SUB + 1];
+    for (int i = 0; i <= nsub; i++) f0[i] = (int)((long long)nframes * i / nsub);
+    for (int i = 0; i < nsub; i++) {
+        st[i] = i == 0 ? s : h->aux[i - 1];
+        sp[i] = P;
+        sw[i] = h->work;
+        const long long o = f0[i];
+        for (int l = 0; l < h->nlevels; l++) sp[i].lv[l].base = P.lv[l].base + o * P.lv[l].frame_stride;
+        sw[i].cand += o * P.cand_frame; sw[i].owner += o * P.cand_frame; sw[i].arena += o * P.arena_frame;
+        sw[i].sel += o * P.list_frame; sw[i].nk += o * h->nlevels; sw[i].errflags += o;
+        sw[i].cand_count += o * h->nlevels * ORBX_CNT_STRIDE;
     }
+    if (nsub > 1) {
+        HIPCHK(hipEventRecord(h->ev_fork, s));
+        for (int i = 1; i < nsub; i++) HIPCHK(hipStreamWaitEvent(st[i], h->ev_fork, 0));
+    }
+    if (prof) HIPCHK(hipEventRecord(h->ev[0], s));
+    for (int l = 1; l < h->nlevels; l++)
+        for (int i = 0; i < nsub; i++)
+            orbx_launch_resize(sp[i].lv[l - 1], sp[i].lv[l], h->tabs[l], h->area2[l], f0[i + 1] - f0[i], l == 1 ? src_end : nullptr, st[i]);
     if (prof) HIPCHK(hipEventRecord(h->ev[1], s));
-    orbx_launch_fast(P, h->work, nframes, s);
+    for (int i = 0; i < nsub; i++) orbx_launch_fast(sp[i], sw[i], f0[i + 1] - f0[i], st[i]);
     if (prof) HIPCHK(hipEventRecord(h->ev[2], s));
-    orbx_launch_octree(P, h->work, nframes, h->oct_lds, s);
+    for (int i = 0; i < nsub; i++) orbx_launch_octree(sp[i], sw[i], f0[i + 1] - f0[i], h->oct_lds, st[i]);
     if (prof) HIPCHK(hipEventRecord(h->ev[3], s));
-    orbx_launch_describe(P, h->work, nframes, d_kps, d_desc, d_counts, d_status, s);
+    for (int i = 0; i < nsub; i++)
+        orbx_launch_describe(sp[i], sw[i], f0[i + 1] - f0[i], d_kps + (long long)f0[i] * P.out_cap,
+                             d_desc + (long long)f0[i] * P.out_cap * 32, d_counts + f0[i], d_status + f0[i], st[i]);
     if (prof) HIPCHK(hipEventRecord(h->ev[4], s));
+    for (int i = 1; i < nsub; i++) {
+        HIPCHK(hipEventRecord(h->ev_join[i - 1], st[i]));
+        HIPCHK(hipStreamWaitEvent(s, h->ev_join[i - 1], 0));
+    }
     HIPCHK(hipGetLastError());
     return ORBX_OK;
 }
@@ -480,7 +519,7 @@ extern "C" int orbx_download_level(orbx_extractor *h, int frame, int level, uint
     OrbxLevel L = h->plan.lv[level];
     if (level == 0) { L.base = const_cast<uint8_t *>(h->last_input); L.stride = h->last_in_stride; L.frame_stride = h->last_in_frame; }
     if (dst_stride < L.w + 2 * border) return fail(ORBX_E_INVALID, "dst_stride too small");
-    HIPCHK(hipStreamSynchronize(h->stream));
+    HIPCHK(hipDeviceSynchronize());   // the last call may have run on a caller stream and the aux streams
     uint8_t *interior = dst + (size_t)border * dst_stride + border;
     HIPCHK(hipMemcpy2D(interior, dst_stride, L.base + (size_t)frame * L.frame_stride, L.stride, L.w, L.h, hipMemcpyDeviceToHost));
     if (border > 0) {   // copyMakeBorder(..., BORDER_REFLECT_101), :1127-1133
@@ -502,7 +541,7 @@ extern "C" int orbx_download_candidates(orbx_extractor *h, int frame, int level,
     if (!h || !xyr || level < 0 || level >= h->nlevels || h->cur_w == 0 || frame < 0 || frame >= h->last_batch)
         return fail(ORBX_E_INVALID, "bad download_candidates argument");
     HIPCHK(hipSetDevice(h->device));
-    HIPCHK(hipStreamSynchronize(h->stream));
+    HIPCHK(hipDeviceSynchronize());
     uint32_t n = 0;
     HIPCHK(hipMemcpy(&n, h->work.cand_count + ((size_t)frame * h->nlevels + level) * ORBX_CNT_STRIDE, sizeof(n), hipMemcpyDeviceToHost));
     const OrbxLevel &L = h->plan.lv[level];
