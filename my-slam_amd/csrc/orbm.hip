@@ -201,7 +201,12 @@ __device__ __forceinline__ void three_maxima(const int *histo, int L, int &ind1,
     else if ((float)max3 < 0.1f * (float)max1) { ind3 = -1; }
 }
 
-__global__ __launch_bounds__(M_THREADS) void k_accept_rot(
+// One 1024-thread workgroup per frame pair; every thread keeps its (up to ACC_PER_THREAD) queries in
+// registers across the histogram barrier, so the kernel is two dependent global round trips
+// (partials -> matched keypoint angle) instead of a chain per loop iteration.
+#define ACC_THREADS 1024
+#define ACC_PER_THREAD 4
+__global__ __launch_bounds__(ACC_THREADS) void k_accept_rot(
     const int32_t *__restrict__ nqv, const orbx_keypoint *__restrict__ kq, const orbx_keypoint *__restrict__ kt,
     int cap, const uint2 *__restrict__ part, int S, int th, float nnratio, int check_ori,
     int32_t *__restrict__ match12, int32_t *__restrict__ nmatches,
@@ -217,32 +222,76 @@ __global__ __launch_bounds__(M_THREADS) void k_accept_rot(
     if (tid < 32) hist[tid] = 0;
     if (tid == 0) s_count = 0;
     __syncthreads();
-    for (int i = tid; i < nq; i += M_THREADS) {
-        int bi, bd, sd;
-        merge_partials(part, S, stride_z, base + i, bi, bd, sd);
-        if (best_idx) { best_idx[base + i] = bi; best_d[base + i] = bd; second_d[base + i] = sd; }
-        int m = -1;
-        if (bd <= th && (float)bd < __fmul_rn(nnratio, (float)sd)) m = bi;     // :228-232
-        match12[base + i] = m;
-        if (m >= 0 && check_ori) atomicAdd(&hist[rot_bin(kq[base + i].angle, kt[base + m].angle)], 1);
-    }
-    __syncthreads();
-    if (tid == 0) {
-        int i1, i2, i3;
-        three_maxima(hist, 30, i1, i2, i3);
-        s_ind[0] = i1; s_ind[1] = i2; s_ind[2] = i3;
-    }
-    __syncthreads();
     int cnt = 0;
-    for (int i = tid; i < nq; i += M_THREADS) {
-        int m = match12[base + i];
-        if (m >= 0 && check_ori) {
-            const int bin = rot_bin(kq[base + i].angle, kt[base + m].angle);
-            if (bin != s_ind[0] && bin != s_ind[1] && bin != s_ind[2]) { m = -1; match12[base + i] = -1; }
+    for (int i0 = 0; i0 < nq; i0 += ACC_THREADS * ACC_PER_THREAD) {
+        int mm[ACC_PER_THREAD], bins[ACC_PER_THREAD];
+        float aq[ACC_PER_THREAD];
+#pragma unroll
+        for (int u = 0; u < ACC_PER_THREAD; u++) {
+            const int i = i0 + u * ACC_THREADS + tid;
+            mm[u] = -1; bins[u] = -1; aq[u] = 0.f;
+            if (i < nq) {
+                int bi, bd, sd;
+                merge_partials(part, S, stride_z, base + i, bi, bd, sd);
+                if (best_idx) { best_idx[base + i] = bi; best_d[base + i] = bd; second_d[base + i] = sd; }
+                if (bd <= th && (float)bd < __fmul_rn(nnratio, (float)sd)) mm[u] = bi;     // :228-232
+                if (check_ori) aq[u] = kq[base + i].angle;
+            }
         }
-        cnt += m >= 0;
+#pragma unroll
+        for (int u = 0; u < ACC_PER_THREAD; u++)
+            if (mm[u] >= 0 && check_ori) {
+                bins[u] = rot_bin(aq[u], kt[base + mm[u]].angle);
+                atomicAdd(&hist[bins[u]], 1);
+            }
+        if (nq > ACC_THREADS * ACC_PER_THREAD) {
+            // more queries than one sweep holds in registers: park (match, bin) in match12 and redo below
+#pragma unroll
+            for (int u = 0; u < ACC_PER_THREAD; u++) {
+                const int i = i0 + u * ACC_THREADS + tid;
+                if (i < nq) match12[base + i] = mm[u] >= 0 ? (mm[u] | (max(bins[u], 0) << 24)) : -1;
+            }
+        } else {
+            __syncthreads();
+            if (tid == 0) {
+                int i1, i2, i3;
+                three_maxima(hist, 30, i1, i2, i3);
+                s_ind[0] = i1; s_ind[1] = i2; s_ind[2] = i3;
+            }
+            __syncthreads();
+#pragma unroll
+            for (int u = 0; u < ACC_PER_THREAD; u++) {
+                const int i = i0 + u * ACC_THREADS + tid;
+                if (i < nq) {
+                    int m = mm[u];
+                    if (m >= 0 && check_ori && bins[u] != s_ind[0] && bins[u] != s_ind[1] && bins[u] != s_ind[2]) m = -1;
+                    match12[base + i] = m;
+                    cnt += m >= 0;
+                }
+            }
+        }
     }
-    for (int i = nq + tid; i < cap; i += M_THREADS) match12[base + i] = -1;
+    if (nq > ACC_THREADS * ACC_PER_THREAD) {   // large-frame path (train index < 2^22: cap <= 0x3FFFFF is checked on the host)
+        __syncthreads();
+        if (tid == 0) {
+            int i1, i2, i3;
+            three_maxima(hist, 30, i1, i2, i3);
+            s_ind[0] = i1; s_ind[1] = i2; s_ind[2] = i3;
+        }
+        __syncthreads();
+        for (int i = tid; i < nq; i += ACC_THREADS) {
+            const int pk = match12[base + i];
+            int m = -1;
+            if (pk >= 0) {
+                m = pk & 0xFFFFFF;
+                const int bin = pk >> 24;
+                if (check_ori && bin != s_ind[0] && bin != s_ind[1] && bin != s_ind[2]) m = -1;
+            }
+            match12[base + i] = m;
+            cnt += m >= 0;
+        }
+    }
+    for (int i = nq + tid; i < cap; i += ACC_THREADS) match12[base + i] = -1;
     if (cnt) atomicAdd(&s_count, cnt);
     __syncthreads();
     if (tid == 0) nmatches[b] = s_count;
@@ -438,7 +487,7 @@ extern "C" int orbm_match_batch_device(orbm_matcher *m, const uint8_t *d_q, cons
     int S = 1;
     int rc = launch_dense_batch(m, d_q, d_nq, d_t, d_nt, cap, nbatch, s, &S);
     if (rc != ORBX_OK) return rc;
-    hipLaunchKernelGGL(k_accept_rot, dim3(nbatch), dim3(M_THREADS), 0, s, d_nq, d_kq, d_kt, cap, m->d_part, S,
+    hipLaunchKernelGGL(k_accept_rot, dim3(nbatch), dim3(ACC_THREADS), 0, s, d_nq, d_kq, d_kt, cap, m->d_part, S,
                        th, nnratio, check_orientation, d_match12, d_nmatches,
                        (int32_t *)nullptr, (int32_t *)nullptr, (int32_t *)nullptr);
     MHIPCHK(hipGetLastError());

@@ -74,3 +74,42 @@ def test_extract_then_match_frame_pair(orbx, synth):
     onm, om12 = O.match_dense(d1, k1["angle"], d0, k0["angle"], 50, 0.9, True)
     assert nm == onm and np.array_equal(m12, om12)
     assert nm > 300     # the shifted frame really matches
+
+
+@pytest.mark.parametrize("cap,nqs,nts", [(1100, [1000, 0, 1037], [990, 1100, 1]), (5000, [4500, 4999], [4800, 4097])])
+def test_match_batch_device(orbx, cap, nqs, nts):
+    """Device-resident batched dense match (bench path): acceptance + rotation filter == oracle,
+    including the > 4096-query sweep of k_accept_rot and empty / single-descriptor frames."""
+    import torch
+    rng = np.random.default_rng(cap)
+    nb = len(nqs)
+    q = np.zeros((nb, cap, 32), np.uint8); t = np.zeros((nb, cap, 32), np.uint8)
+    kq = np.zeros((nb, cap), orbx.KP_DTYPE); kt = np.zeros((nb, cap), orbx.KP_DTYPE)
+    for b in range(nb):
+        base = _rand_desc(rng, 400, 60)
+        t[b, :nts[b]] = base[rng.integers(0, 400, nts[b])]
+        q[b, :nqs[b]] = base[rng.integers(0, 400, nqs[b])]
+        flips = rng.integers(0, 256, (nqs[b], 2))
+        for i in range(nqs[b]):
+            for f in flips[i]:
+                q[b, i, f >> 3] ^= np.uint8(1 << (f & 7))
+        kt[b]["angle"] = rng.uniform(0, 360, cap).astype(np.float32)
+        kq[b]["angle"] = (kt[b]["angle"][rng.integers(0, max(nts[b], 1), cap)] + np.float32(20.0)) % np.float32(360.0)
+    dq, dt = torch.from_numpy(q).cuda(), torch.from_numpy(t).cuda()
+    dkq = torch.from_numpy(kq.view(np.float32).reshape(nb, cap, 7)).cuda()
+    dkt = torch.from_numpy(kt.view(np.float32).reshape(nb, cap, 7)).cuda()
+    dnq = torch.tensor(nqs, dtype=torch.int32).cuda(); dnt = torch.tensor(nts, dtype=torch.int32).cuda()
+    m12 = torch.zeros((nb, cap), dtype=torch.int32).cuda(); nm = torch.zeros(nb, dtype=torch.int32).cuda()
+    m = orbx.ORBmatcher(0.9, True, max_queries=cap, max_train=cap, max_pairs=1)
+    st = torch.cuda.Stream()
+    with torch.cuda.stream(st):
+        m.match_batch_device(dq.data_ptr(), dkq.data_ptr(), dnq.data_ptr(), dt.data_ptr(), dkt.data_ptr(), dnt.data_ptr(),
+                             cap, nb, m12.data_ptr(), nm.data_ptr(), stream=st.cuda_stream)
+    st.synchronize()
+    m12h, nmh = m12.cpu().numpy(), nm.cpu().numpy()
+    for b in range(nb):
+        on, om = O.match_dense(q[b, :nqs[b]], kq[b]["angle"][:nqs[b]], t[b, :nts[b]], kt[b]["angle"][:nts[b]], 50, 0.9, True) \
+            if nqs[b] > 0 else (0, np.zeros(0, np.int32))
+        assert nmh[b] == on
+        assert np.array_equal(m12h[b, :nqs[b]], om)
+        assert (m12h[b, nqs[b]:] == -1).all()
