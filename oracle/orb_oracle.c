@@ -62,6 +62,15 @@ void oro_sincos_deg(float angle_deg, float *a_cos, float *b_sin)
     *b_sin = (float)sinl((long double)angle);
 }
 
+/* array form on radians (tools/verify_sincos.py: exhaustive check of the device routine) */
+void oro_sincos_rad_array(const float *theta, float *c, float *s, long long n)
+{
+    for (long long i = 0; i < n; i++) {
+        c[i] = (float)cosl((long double)theta[i]);
+        s[i] = (float)sinl((long double)theta[i]);
+    }
+}
+
 /* OpenCV 3.1.0: borderInterpolate(p, len, BORDER_REFLECT_101): -k -> k, len-1+k -> len-1-k */
 int oro_reflect101(int p, int len)
 {

@@ -71,6 +71,7 @@ const signed char *oro_pattern(void);           /* 1024 int8 */
 int oro_cv_round(double v);                     /* cvRound: round half to even */
 float oro_fast_atan2(float y, float x);         /* cv::fastAtan2, degrees */
 void oro_sincos_deg(float angle_deg, float *a_cos, float *b_sin); /* :114-115, correctly rounded */
+void oro_sincos_rad_array(const float *theta, float *c, float *s, long long n);
 int oro_reflect101(int p, int len);
 void oro_resize_linear(const uint8_t *src, int sw, int sh, int sstride,
                        uint8_t *dst, int dw, int dh, int dstride);
