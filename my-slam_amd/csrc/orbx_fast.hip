@@ -30,7 +30,7 @@ template <int TS, int TH, int ZS>   // tile row stride (bytes, multiple of 4), t
 struct FastLds {
     uint8_t tile[TS * TH];
     uint8_t smap[ZS * ZS];
-    uint16_t queue[256];
+    uint16_t queue[392];   // < 128 pending + <= 256 appended per stage-1 step; [391] = trash slot
     uint16_t clist[FAST_CLIST];
     unsigned long long masks[(ZS * ZS + 63) / 64];
 };
@@ -172,7 +172,6 @@ __global__ __launch_bounds__(FAST_THREADS) void k_fast_cells(OrbxPlan plan, Orbx
             for (int i = lane; i < nz; i += 64) z[i] = 0;
         }
         WSYNC();
-        if (plan.dbg == 1) return;
 
         // ---- stages 1+2.  Stage-1 task = (zone row, dword group): 4 horizontally adjacent pixels ----
         const us2 tt = as_us2((uint32_t)t_lo * 0x00010001u);
@@ -191,13 +190,13 @@ __global__ __launch_bounds__(FAST_THREADS) void k_fast_cells(OrbxPlan plan, Orbx
         } else cl_over = true;                                                                                       \
     } while (0)
         for (int base = 0; base < ntask; base += 64) {
-            const int t = base + lane;
-            uint32_t f01 = 0, f23 = 0;
-            int zy = 0, zx0 = 0;
-            if (t < ntask) {
-                zy = (int)(((uint32_t)t * rcpg) >> 16);
-                const int g = g0 + (t - zy * ng);
-                zx0 = 4 * g - cb;                                    // zone column of byte 0 of this group
+            // lanes past the last task redo the last one; their pixels are masked out through zx0
+            const int t = min(base + lane, ntask - 1);
+            const int zy = (int)(((uint32_t)t * rcpg) >> 16);
+            const int g = g0 + (t - zy * ng);
+            const int zx0 = (base + lane < ntask) ? 4 * g - cb : -1000;   // zone column of byte 0 of this group
+            uint32_t f01, f23;
+            {
                 const uint32_t *r0 = reinterpret_cast<const uint32_t *>(&S.tile[(zy + 3) * TS]) + g;
                 const uint32_t *rp = reinterpret_cast<const uint32_t *>(&S.tile[(zy + 5) * TS]) + g;
                 const uint32_t *rm = reinterpret_cast<const uint32_t *>(&S.tile[(zy + 1) * TS]) + g;
@@ -215,34 +214,41 @@ __global__ __launch_bounds__(FAST_THREADS) void k_fast_cells(OrbxPlan plan, Orbx
                 f01 = reject8(lo2(cC), tt, lo2(dD), lo2(dU), lo2(d4), lo2(d12), lo2(d2), lo2(d10), lo2(d6), lo2(d14));
                 f23 = reject8(hi2(cC), tt, hi2(dD), hi2(dU), hi2(d4), hi2(d12), hi2(d2), hi2(d10), hi2(d6), hi2(d14));
             }
-#pragma unroll
-            for (int j = 0; j < 4; j++) {
-                const uint32_t fl = (j < 2 ? f01 : f23) & ((j & 1) ? 0xFFFF0000u : 0x0000FFFFu);
-                const int zx = zx0 + j;
-                const bool ok = fl != 0 && zx >= 0 && zx < zw;
-                const unsigned long long m = __ballot(ok);
-                if (ok) S.queue[qn + __popcll(m & ((1ull << lane) - 1ull))] = (uint16_t)((zy << 6) | zx);
-                qn += __popcll(m);
-                if (qn >= 128 && plan.dbg == 2) qn -= 128;
-                if (qn >= 128) {
-                    WSYNC();
-                    DRAIN(128);
-                    const int rest = qn - 128;            // move the tail of the queue to the front
+            // append the survivors of the 4 pixels: four ballots, one queue update (entry order is free)
+            const bool k0 = (f01 & 0x0000FFFFu) != 0 && zx0 >= 0 && zx0 < zw;
+            const bool k1 = (f01 & 0xFFFF0000u) != 0 && zx0 + 1 >= 0 && zx0 + 1 < zw;
+            const bool k2 = (f23 & 0x0000FFFFu) != 0 && zx0 + 2 >= 0 && zx0 + 2 < zw;
+            const bool k3 = (f23 & 0xFFFF0000u) != 0 && zx0 + 3 >= 0 && zx0 + 3 < zw;
+            const unsigned long long b0 = __ballot(k0), b1 = __ballot(k1), b2 = __ballot(k2), b3 = __ballot(k3);
+            const unsigned long long lt = (1ull << lane) - 1ull;
+            const int n0 = __popcll(b0), n1 = __popcll(b1), n2 = __popcll(b2);
+            const int e0 = qn + __popcll(b0 & lt), e1 = qn + n0 + __popcll(b1 & lt);
+            const int e2 = qn + n0 + n1 + __popcll(b2 & lt), e3 = qn + n0 + n1 + n2 + __popcll(b3 & lt);
+            const int pz = (zy << 6) + zx0;          // (zy << 6) | zx for every pixel with 0 <= zx < 64
+            S.queue[k0 ? e0 : 391] = (uint16_t)pz;
+            S.queue[k1 ? e1 : 391] = (uint16_t)(pz + 1);
+            S.queue[k2 ? e2 : 391] = (uint16_t)(pz + 2);
+            S.queue[k3 ? e3 : 391] = (uint16_t)(pz + 3);
+            qn += n0 + n1 + n2 + __popcll(b3);
+            while (qn >= 128) {
+                WSYNC();
+                DRAIN(128);
+                const int rest = qn - 128;            // move the tail of the queue to the front
+                WSYNC();
+                for (int i0 = 0; i0 < rest; i0 += 64) {   // rest < 256: ascending blocks never overwrite unread entries
                     uint16_t tmpq = 0;
-                    if (lane < rest) tmpq = S.queue[128 + lane];
+                    if (i0 + lane < rest) tmpq = S.queue[128 + i0 + lane];
                     WSYNC();
-                    if (lane < rest) S.queue[lane] = tmpq;
-                    qn = rest;
+                    if (i0 + lane < rest) S.queue[i0 + lane] = tmpq;
                     WSYNC();
                 }
+                qn = rest;
             }
         }
         WSYNC();
-        if (plan.dbg == 2) { if (qn == 12345) wk.errflags[f] = 1; return; }
         DRAIN(qn);   // the remaining survivors (qn < 128)
 #undef DRAIN
         WSYNC();
-        if (plan.dbg == 3) { if (ncl == 12345) wk.errflags[f] = 1; return; }
 
         // ---- stage 3: NMS (strictly greater than all 8 neighbours; outside the cell zone counts as 0).
         // Items are the listed corners, or every zone pixel if the list overflowed. ----
@@ -266,13 +272,10 @@ __global__ __launch_bounds__(FAST_THREADS) void k_fast_cells(OrbxPlan plan, Orbx
             if (lane == 0) S.masks[it] = mm;
             total += __popcll(mm);
         }
-        if (plan.dbg == 5) { if (total == 12345) wk.errflags[f] = 1; return; }
         if (total == 0) continue;   // nothing at this threshold: fall back to the lower one
-        if (plan.dbg == 6) { if (total == 12345) wk.errflags[f] = 1; return; }
 
         int gbase = 0;
-        if (lane == 0 && plan.dbg != 7) gbase = (int)atomicAdd(&ORBX_CNT(wk, plan, f, l), (uint32_t)total);
-        if (plan.dbg == 7) gbase = (c * 7) % (L.cand_cap - 64);
+        if (lane == 0) gbase = (int)atomicAdd(&ORBX_CNT(wk, plan, f, l), (uint32_t)total);
         gbase = __shfl(gbase, 0);
         WSYNC();
         OrbxCand *out = wk.cand + (long long)f * plan.cand_frame + L.cand_off;
