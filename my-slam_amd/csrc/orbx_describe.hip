@@ -199,8 +199,7 @@ __global__ __launch_bounds__(256) void k_describe(
 #pragma unroll
         for (int p = 0; p < 9; p++) {
             const uint32_t hi = __shfl_down(gv[p], 1);
-            const uint32_t v = xo == 0 ? gv[p] : xo == 1 ? __builtin_amdgcn_alignbyte(hi, gv[p], 1)
-                             : xo == 2 ? __builtin_amdgcn_alignbyte(hi, gv[p], 2) : __builtin_amdgcn_alignbyte(hi, gv[p], 3);
+            const uint32_t v = __builtin_amdgcn_alignbyte(hi, gv[p], (uint32_t)xo);
             const int r = p * 5 + rr;
             if (lane < 60 && r < 43 && d < 11) *reinterpret_cast<uint32_t *>(&S.raw[r * DW_RAW_STRIDE + 4 * d]) = v;
         }
@@ -302,19 +301,15 @@ __global__ __launch_bounds__(256) void k_describe(
                     const uint32_t o0 = D2(w[0].x, K_0, D2(w[1].x, K12, D2(w[2].x, K34, D2(w[3].x, K56, 0u))));
                     const uint32_t o1 = D2(w[0].y, K_0, D2(w[1].y, K12, D2(w[2].y, K34, D2(w[3].y, K56, 0u))));
 #undef D2
-                    uint32_t s4[4] = {e0, e1, o0, o1};
+                    const uint32_t s4[4] = {e0, e1, o0, o1};
                     uint32_t v4[4];
 #pragma unroll
                     for (int z = 0; z < 4; z++) {
-                        const int col = x - DESC_R + c + (z & 1);
-                        uint32_t v;
-                        if (col < simd_cols) {        // OpenCV x86 SSE2 column path: round half to even
-                            v = s4[z] >> 16;
-                            const uint32_t rem = s4[z] & 0xFFFFu;
-                            if (rem > 0x8000u || (rem == 0x8000u && (v & 1u))) v++;
-                        } else {                      // OpenCV portable C path: (sum + 32768) >> 16
-                            v = (s4[z] + 32768u) >> 16;
-                        }
+                        // OpenCV portable C path: (sum + 32768) >> 16; x86 SSE2 path (columns < simd_cols): the
+                        // same except that an exact .5 tie rounds to even -- branch-free select
+                        uint32_t v = (s4[z] + 32768u) >> 16;
+                        const bool tie_to_even = (x - DESC_R + c + (z & 1) < simd_cols) && ((s4[z] & 0xFFFFu) == 0x8000u) && (v & 1u);
+                        v -= tie_to_even ? 1u : 0u;
                         v4[z] = min(v, 255u);
                     }
                     *reinterpret_cast<uint16_t *>(&bl[(2 * q) * DW_BL_STRIDE + c]) = (uint16_t)(v4[0] | (v4[1] << 8));

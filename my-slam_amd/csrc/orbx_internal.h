@@ -17,7 +17,9 @@
 #define ORBX_CNT_STRIDE 32
 #define ORBX_CNT(wk, plan, f, l) ((wk).cand_count[((f) * (plan).nlevels + (l)) * ORBX_CNT_STRIDE])
 
+#ifndef OCT_THREADS
 #define OCT_THREADS 512
+#endif
 #define OCT_ID_MASK 0x3FFFFFFFu
 
 #define DESC_THREADS 64
