@@ -49,6 +49,12 @@ def lib():
         return _lib
     if not os.path.exists(LIB_PATH):
         raise OrbxError(ORBX_E_HIP, "%s is missing: run __graft_entry__.build() / make -C my-slam_amd" % LIB_PATH)
+    try:
+        # PyTorch-ROCm wheels carry their own libamdhip64; whichever copy is mapped first serves the whole
+        # process.  Loading torch first keeps `torch.cuda` usable next to liborbx (bench.py, tests).
+        import torch  # noqa: F401
+    except Exception:
+        pass
     L = C.CDLL(LIB_PATH)
     vp, ip = C.c_void_p, C.POINTER(C.c_int)
     L.orbx_create.argtypes = [C.POINTER(vp), C.c_int, C.c_float, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]

@@ -1,9 +1,9 @@
 // orbm.hip -- gfx950 Hamming matcher primitives + their C ABI (include/orbm.h).
 // Reference: src/ORBmatcher.cc of WChen09/My-SLAM (DescriptorDistance :1647-1663, best/second-best
 // loops :201-232 and siblings, ComputeThreeMaxima :1601-1642).  Integer/bitwise only: v_xor_b32 +
-// v_bcnt_u32_b32 (popcount with accumulate); in the dense kernel the train descriptor of a step is
-// wave-uniform and comes through the scalar cache, so the kernel is VALU-bound, not HBM-bound
-// (16 M pairs touch 256 KB).
+// v_bcnt_u32_b32 (popcount with accumulate); the train set goes through LDS tiles and is read back as
+// wave-uniform broadcasts, so the kernel is VALU-bound, not HBM-bound (16 M pairs
+// touch 256 KB).
 #include <algorithm>
 #include <cmath>
 #include <cstdarg>
@@ -48,20 +48,22 @@ __device__ __forceinline__ int hamming256(const uint4 &a0, const uint4 &a1, cons
     return d;
 }
 
-// ---- dense best/second-best: one query per thread (8 VGPRs); the train descriptor of a step is
-// wave-uniform, so it arrives through the scalar cache (s_load_dwordx8) and feeds v_xor_b32 as an
-// SGPR operand: no LDS, no barrier.  gridDim.z splits the train range; every split writes a partial
+// ---- dense best/second-best: one query per thread (8 VGPRs); the train range of a workgroup is
+// staged through double-buffered 4 KiB LDS tiles and read back as wave-uniform broadcasts
+// (2 x ds_read_b128 per pair against 22 VALU ops).  gridDim.z splits the train range for occupancy; every split writes a partial
 // (best key, second key) with key = distance << 22 | train index, so "strictly smaller wins, first
 // index wins a tie, a tie with the best becomes the second best" (src/ORBmatcher.cc:214-223) is
 // min / median on keys and partials merge exactly (k_merge_best2 / k_accept_rot). ----
 #define M_KEY_NONE ((256u << 22) | 0x3FFFFFu)
 __device__ __forceinline__ uint32_t med3u(uint32_t a, uint32_t b, uint32_t c) { return max(min(a, b), min(max(a, b), c)); }
 
+#define M_TILE 128   // train descriptors staged per LDS tile (4 KiB)
 __global__ __launch_bounds__(M_THREADS) void k_best2_dense(
     const uint8_t *__restrict__ q, const int32_t *__restrict__ nqv, int nq_fixed,
     const uint8_t *__restrict__ t, const int32_t *__restrict__ ntv, int nt_fixed,
     long long qstride, long long tstride, int out_stride, uint2 *__restrict__ part)
 {
+    __shared__ uint4 tile[2][M_TILE * 2];
     const int b = blockIdx.y, tid = threadIdx.x;
     const int nq = nqv ? nqv[b] : nq_fixed;
     const int nt = ntv ? ntv[b] : nt_fixed;
@@ -74,12 +76,24 @@ __global__ __launch_bounds__(M_THREADS) void k_best2_dense(
     uint4 q0 = make_uint4(0, 0, 0, 0), q1 = q0;
     if (qi < nq) { q0 = Q[2 * qi]; q1 = Q[2 * qi + 1]; }
     uint32_t bk = M_KEY_NONE, sk = M_KEY_NONE;
+    // double-buffered tiles: the loads of tile k+1 are in flight while tile k is scanned
+    int cnt = min(M_TILE, j1 - j0);
+    if (tid < cnt * 2) tile[0][tid] = T[2 * j0 + tid];
+    int buf = 0;
+    for (int t0 = j0; t0 < j1; t0 += M_TILE) {
+        const int ncnt = min(M_TILE, j1 - (t0 + M_TILE));
+        uint4 pre = make_uint4(0, 0, 0, 0);
+        if (tid < ncnt * 2) pre = T[2 * (t0 + M_TILE) + tid];
+        __syncthreads();
 #pragma unroll 4
-    for (int j = j0; j < j1; j++) {
-        const uint4 a0 = T[2 * j], a1 = T[2 * j + 1];      // uniform address: scalar loads
-        const uint32_t key = ((uint32_t)hamming256(q0, q1, a0, a1) << 22) | (uint32_t)j;
-        sk = med3u(bk, sk, key);                            // second smallest of {bk <= sk, key}
-        bk = min(bk, key);
+        for (int j = 0; j < cnt; j++) {
+            const uint32_t key = ((uint32_t)hamming256(q0, q1, tile[buf][2 * j], tile[buf][2 * j + 1]) << 22) | (uint32_t)(t0 + j);
+            sk = med3u(bk, sk, key);                            // second smallest of {bk <= sk, key}
+            bk = min(bk, key);
+        }
+        if (tid < ncnt * 2) tile[buf ^ 1][tid] = pre;
+        buf ^= 1;
+        cnt = ncnt;
     }
     if (qi < nq) part[((long long)blockIdx.z * gridDim.y + b) * out_stride + qi] = make_uint2(bk, sk);
 }
