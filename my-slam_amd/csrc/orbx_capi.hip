@@ -46,6 +46,7 @@ struct orbx_extractor {
     int quota[ORBX_MAX_LEVELS];
     int umax[16]; int gauss_k[7];
     int blur_mode = 0;
+    bool need_clear = true;
     hipStream_t stream = nullptr;
     hipStream_t aux[ORBX_MAX_SUB - 1] = {}; hipEvent_t ev_fork = nullptr, ev_join[ORBX_MAX_SUB - 1] = {}; int nsub = 1;
     // current plan
@@ -181,7 +182,7 @@ static void free_all(orbx_extractor *h)
     hipSetDevice(h->device);
     hipFree(h->d_input); hipFree(h->d_pyr); hipFree(h->d_tab_i); hipFree(h->d_tab_s);
     hipFree(h->work.cand); hipFree(h->work.cand_count); hipFree(h->work.owner); hipFree(h->work.arena);
-    hipFree(h->work.sel); hipFree(h->work.nk); hipFree(h->work.errflags);
+    hipFree(h->work.sel); hipFree(h->work.nk); hipFree(h->work.ncand); hipFree(h->work.errflags);
     hipFree(h->d_kps); hipFree(h->d_desc); hipFree(h->d_counts); hipFree(h->d_status);
     hipHostFree(h->h_kps); hipHostFree(h->h_desc); hipHostFree(h->h_counts); hipHostFree(h->h_status);
     for (auto &e : h->ev) if (e) hipEventDestroy(e);
@@ -249,6 +250,7 @@ extern "C" int orbx_create(orbx_extractor **out, int nfeatures, float scale_fact
     ALLOC(h->work.sel, B * M.list_frame * sizeof(OrbxCand));
     ALLOC(h->work.cand_count, B * ORBX_MAX_LEVELS * ORBX_CNT_STRIDE * sizeof(uint32_t));
     ALLOC(h->work.nk, B * ORBX_MAX_LEVELS * sizeof(uint32_t));
+    ALLOC(h->work.ncand, B * ORBX_MAX_LEVELS * sizeof(uint32_t));
     ALLOC(h->work.errflags, B * sizeof(uint32_t));
     ALLOC(h->d_kps, B * M.out_cap * sizeof(orbx_keypoint));
     ALLOC(h->d_desc, B * M.out_cap * 32);
@@ -369,8 +371,12 @@ static int enqueue(orbx_extractor *h, const uint8_t *d_images, int nframes, int 
     h->last_input = d_images; h->last_in_stride = row_stride; h->last_in_frame = frame_stride; h->last_batch = nframes;
 
     const bool prof = h->profiling != 0;
-    HIPCHK(hipMemsetAsync(h->work.cand_count, 0, (size_t)nframes * h->nlevels * ORBX_CNT_STRIDE * sizeof(uint32_t), s));
-    HIPCHK(hipMemsetAsync(h->work.errflags, 0, (size_t)nframes * sizeof(uint32_t), s));
+    if (h->need_clear) {   // the kernels leave the counters and flags zeroed; only the first call (or one after an error) clears
+        HIPCHK(hipMemsetAsync(h->work.cand_count, 0, (size_t)h->max_batch * ORBX_MAX_LEVELS * ORBX_CNT_STRIDE * sizeof(uint32_t), s));
+        HIPCHK(hipMemsetAsync(h->work.errflags, 0, (size_t)h->max_batch * sizeof(uint32_t), s));
+        h->need_clear = false;
+    }
+    struct DirtyGuard { orbx_extractor *h; bool ok = false; ~DirtyGuard() { if (!ok) h->need_clear = true; } } guard{h};
     const uint8_t *src_end = nullptr;   // level 0 in caller memory has no slack behind its last byte
     if (d_images != h->d_input)
         src_end = d_images + (long long)(nframes - 1) * frame_stride + (long long)(H - 1) * row_stride + W;
@@ -391,7 +397,7 @@ static int enqueue(orbx_extractor *h, const uint8_t *d_images, int nframes, int 
         const long long o = f0[i];
         for (int l = 0; l < h->nlevels; l++) sp[i].lv[l].base = P.lv[l].base + o * P.lv[l].frame_stride;
         sw[i].cand += o * P.cand_frame; sw[i].owner += o * P.cand_frame; sw[i].arena += o * P.arena_frame;
-        sw[i].sel += o * P.list_frame; sw[i].nk += o * h->nlevels; sw[i].errflags += o;
+        sw[i].sel += o * P.list_frame; sw[i].nk += o * h->nlevels; sw[i].ncand += o * h->nlevels; sw[i].errflags += o;
         sw[i].cand_count += o * h->nlevels * ORBX_CNT_STRIDE;
     }
     if (nsub > 1) {
@@ -416,6 +422,7 @@ static int enqueue(orbx_extractor *h, const uint8_t *d_images, int nframes, int 
         HIPCHK(hipStreamWaitEvent(s, h->ev_join[i - 1], 0));
     }
     HIPCHK(hipGetLastError());
+    guard.ok = true;
     return ORBX_OK;
 }
 
@@ -543,7 +550,7 @@ extern "C" int orbx_download_candidates(orbx_extractor *h, int frame, int level,
     HIPCHK(hipSetDevice(h->device));
     HIPCHK(hipDeviceSynchronize());
     uint32_t n = 0;
-    HIPCHK(hipMemcpy(&n, h->work.cand_count + ((size_t)frame * h->nlevels + level) * ORBX_CNT_STRIDE, sizeof(n), hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(&n, h->work.ncand + (size_t)frame * h->nlevels + level, sizeof(n), hipMemcpyDeviceToHost));
     const OrbxLevel &L = h->plan.lv[level];
     n = std::min<uint32_t>(n, (uint32_t)L.cand_cap);
     if ((int)n > cap) return fail(ORBX_E_CAPACITY, "%u candidates, capacity %d", n, cap);

@@ -164,6 +164,7 @@ __global__ __launch_bounds__(256) void k_describe(
     }
     if (g == 0 && lane == 0) {
         const uint32_t e = wk.errflags[f];
+        wk.errflags[f] = 0;   // self-cleaning for the next call
         counts[f] = min(total, plan.out_cap);
         status[f] = (e & ERRF_CAND_OVERFLOW) ? ORBX_E_CAND_OVERFLOW
                   : (e & ERRF_TREE_OVERFLOW) ? ORBX_E_TREE_OVERFLOW

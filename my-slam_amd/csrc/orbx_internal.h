@@ -76,6 +76,7 @@ struct OrbxWork {                 // device workspace pointers (per handle)
     uint32_t *owner;              // [B][cand_frame]  quadtree: key -> node id (| quadrant << 30)
     OrbxNode *arena;              // [B][arena_frame]
     OrbxCand *sel;                // [B][list_frame]  selected keypoints per level, list order
+    uint32_t *ncand;              // [B][L]           candidates per level of the last call (copy for the debug tap)
     uint32_t *nk;                 // [B][L]           selected per level
     uint32_t *errflags;           // [B]
 };

@@ -84,6 +84,11 @@ __global__ __launch_bounds__(OCT_THREADS) void k_octree(OrbxPlan plan, OrbxWork 
     OrbxNode *arena = wk.arena + (long long)f * plan.arena_frame + L.arena_off;
     OrbxCand *sel = wk.sel + (long long)f * plan.list_frame + L.list_off;
     const int n = (int)min(ORBX_CNT(wk, plan, f, l), (uint32_t)L.cand_cap);
+    __syncthreads();
+    if (tid == 0) {   // self-cleaning: the counter is zero again for the next call (no memset on the hot path)
+        wk.ncand[f * plan.nlevels + l] = (uint32_t)n;
+        ORBX_CNT(wk, plan, f, l) = 0;
+    }
 
     if (n == 0 || L.nIni <= 0) {
         if (tid == 0) wk.nk[f * plan.nlevels + l] = 0;
