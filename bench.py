@@ -105,12 +105,18 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: liborbx has no CPU path")
+    ndev = torch.cuda.device_count()
+    local = local % max(ndev, 1)          # rehearsal with more ranks than GPUs (ORBX_BENCH_BACKEND=gloo)
     torch.cuda.set_device(local)
     dist = None
+    backend = os.environ.get("ORBX_BENCH_BACKEND", "nccl")
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     pkg = load_pkg()
     import my_slam_amd.synth as synth
@@ -124,17 +130,25 @@ def main():
     if args.subbatches:
         ex.set_subbatches(args.subbatches)
     cap = ex.cap
-    kps = torch.zeros((B, cap, 7), dtype=torch.float32, device="cuda")
-    desc = torch.zeros((B, cap, 32), dtype=torch.uint8, device="cuda")
-    counts = torch.zeros(B, dtype=torch.int32, device="cuda")
+    # One flat result buffer per pipeline slot: [B][cap] 28-B keypoints | [B][cap][32] descriptors | [B] counts,
+    # so that one gather moves a whole step's results.  Two slots: the gather of step i overlaps step i+1.
+    nb_k, nb_d = B * cap * 28, B * cap * 32
+    nbytes = nb_k + nb_d + B * 4
+    nslot = 2 if world > 1 else 1
+    outbuf = [torch.zeros(nbytes, dtype=torch.uint8, device="cuda") for _ in range(nslot)]
+    kps_v = [o[:nb_k].view(torch.float32).view(B, cap, 7) for o in outbuf]
+    desc_v = [o[nb_k:nb_k + nb_d].view(B, cap, 32) for o in outbuf]
+    cnt_v = [o[nb_k + nb_d:].view(torch.int32) for o in outbuf]
+    kps, desc, counts = kps_v[0], desc_v[0], cnt_v[0]
     status = torch.zeros(B, dtype=torch.int32, device="cuda")
     matcher = pkg.ORBmatcher(0.9, True, device=local, max_queries=cap, max_train=cap, max_pairs=1) if do_match else None
     match12 = torch.full((B, cap), -1, dtype=torch.int32, device="cuda")
     nmatch = torch.zeros(B, dtype=torch.int32, device="cuda")
     gather_bufs = None
     if world > 1 and rank == 0:
-        gather_bufs = ([torch.empty_like(kps) for _ in range(world)], [torch.empty_like(desc) for _ in range(world)],
-                       [torch.empty_like(counts) for _ in range(world)])
+        gather_bufs = [[torch.empty_like(outbuf[0], device="cuda" if backend == "nccl" else "cpu") for _ in range(world)]
+                       for _ in range(nslot)]
+    pending = [None] * nslot
 
     # one explicit (non-default) stream carries the whole path, so extract -> match -> gather are
     # ordered by the stream itself (a NULL stream would select each handle's private stream)
@@ -142,21 +156,37 @@ def main():
     torch.cuda.set_stream(stream)
     s = stream.cuda_stream
     assert s != 0
+    step_no = [0]
 
     def step():
+        k = step_no[0] % nslot
+        step_no[0] += 1
+        if pending[k] is not None:         # the gather that last read this slot must be done before it is rewritten
+            pending[k].wait()
+            pending[k] = None
+        kp, de, cn = kps_v[k], desc_v[k], cnt_v[k]
         ex.extract_batch_device(frames.data_ptr(), B, W, H, frames.stride(1), frames.stride(0),
-                                kps.data_ptr(), desc.data_ptr(), counts.data_ptr(), status.data_ptr(), s)
+                                kp.data_ptr(), de.data_ptr(), cn.data_ptr(), status.data_ptr(), s)
         if do_match:   # frame k (query) against frame k-1 (train), k = 1..B-1
-            matcher.match_batch_device(desc.data_ptr() + cap * 32, kps.data_ptr() + cap * 28, counts.data_ptr() + 4,
-                                       desc.data_ptr(), kps.data_ptr(), counts.data_ptr(), cap, B - 1,
+            matcher.match_batch_device(de.data_ptr() + cap * 32, kp.data_ptr() + cap * 28, cn.data_ptr() + 4,
+                                       de.data_ptr(), kp.data_ptr(), cn.data_ptr(), cap, B - 1,
                                        match12.data_ptr() + cap * 4, nmatch.data_ptr() + 4, stream=s)
         if world > 1:  # RCCL over xGMI: results back to rank 0, nothing else crosses GPUs
-            dist.gather(kps, gather_bufs[0] if rank == 0 else None, dst=0)
-            dist.gather(desc, gather_bufs[1] if rank == 0 else None, dst=0)
-            dist.gather(counts, gather_bufs[2] if rank == 0 else None, dst=0)
+            if backend == "nccl":
+                pending[k] = dist.gather(outbuf[k], gather_bufs[k] if rank == 0 else None, dst=0, async_op=True)
+            else:          # CPU rehearsal of the same plumbing (gloo has no GPU gather)
+                stream.synchronize()
+                dist.gather(outbuf[k].cpu(), gather_bufs[k] if rank == 0 else None, dst=0)
+
+    def drain():
+        for k in range(nslot):
+            if pending[k] is not None:
+                pending[k].wait()
+                pending[k] = None
 
     for _ in range(args.warmup):
         step()
+    drain()
     torch.cuda.synchronize()
     if int(status.abs().sum().item()) != 0:
         raise SystemExit("device status nonzero: %s" % status.tolist())
@@ -166,18 +196,19 @@ def main():
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
+    drain()                      # every gather has landed on rank 0 inside the timed region
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     nk_local = int(counts.sum().item())
     nm_local = int(nmatch.sum().item()) if do_match else 0
-    tot = torch.tensor([nk_local, nm_local], dtype=torch.int64, device="cuda")
+    tot = torch.tensor([nk_local, nm_local], dtype=torch.int64, device="cuda" if (world == 1 or backend == "nccl") else "cpu")
     if world > 1:
         dist.all_reduce(tot)
     nk_all, nm_all = int(tot[0].item()), int(tot[1].item())
