@@ -82,6 +82,35 @@ int orbm_match_batch_device(orbm_matcher *m, const uint8_t *d_q, const orbx_keyp
                             int check_orientation, int32_t *d_match12, int32_t *d_nmatches,
                             void *hip_stream);
 
+/*
+ * ---- "next" row N1: the Frame grid behind every windowed search ----
+ * src/Frame.cc:230-245 AssignFeaturesToGrid, :382-392 PosInGrid, :327-380 GetFeaturesInArea, and the
+ * scan they feed in ORBmatcher::SearchByProjection (src/ORBmatcher.cc:1397-1430) / SearchForInitialization
+ * (:425-457).  FRAME_GRID_COLS x FRAME_GRID_ROWS = 64 x 48 (include/Frame.h:37-38).
+ *
+ * orbm_grid_build   builds the 64x48 cell lists of one frame on the GPU from its undistorted keypoints
+ *                   (mvKeysUn; with the shipped calibration k1 = 0 that is mvKeys, src/Frame.cc:406-410).
+ *                   Bounds are mnMinX/mnMaxX/mnMinY/mnMaxY (:436-463).  The grid stays in the handle.
+ * orbm_features_in_area   GetFeaturesInArea for nq windows in one call: CSR lists in the reference's
+ *                   order (cell columns, cell rows, push_back order).  Returns the total count.
+ * orbm_search_area_best2  the fused form: window query + best / second-best DescriptorDistance with
+ *                   the strict-'<' tie rules; skip[i] != 0 drops train keypoint i (the reference's
+ *                   `continue` predicates).  *_device takes device pointers and does not synchronise.
+ */
+int orbm_grid_build(orbm_matcher *m, const orbx_keypoint *kps_un, int n,
+                    float min_x, float max_x, float min_y, float max_y);
+int orbm_features_in_area(orbm_matcher *m, const float *x, const float *y, const float *r,
+                          const int32_t *min_level, const int32_t *max_level, int nq,
+                          int32_t *cand_off, int32_t *cand_idx, int cap_idx);
+int orbm_search_area_best2(orbm_matcher *m, const uint8_t *qdesc, const float *x, const float *y, const float *r,
+                           const int32_t *min_level, const int32_t *max_level, int nq,
+                           const uint8_t *train_desc, const uint8_t *skip,
+                           int32_t *best_idx, int32_t *best_d, int32_t *second_d);
+int orbm_search_area_best2_device(orbm_matcher *m, const uint8_t *d_qdesc, const float *d_x, const float *d_y,
+                                  const float *d_r, const int32_t *d_min_level, const int32_t *d_max_level, int nq,
+                                  const uint8_t *d_train_desc, const uint8_t *d_skip,
+                                  int32_t *d_best_idx, int32_t *d_best_d, int32_t *d_second_d, void *hip_stream);
+
 /* Host helpers: ComputeThreeMaxima (ind[3], -1 = none) and the histogram cull over match12. */
 int orbm_three_maxima(const int32_t *hist_sizes, int L, int32_t ind[3]);
 int orbm_rot_filter(const float *angle_q, const float *angle_t, int32_t *match12, int nq);

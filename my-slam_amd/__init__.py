@@ -101,11 +101,16 @@ def _bind_matcher(L):
     L.orbm_distances.argtypes = [vp, vp, C.c_int, vp, C.c_int, vp, vp, vp]
     L.orbm_best2_batch_device.argtypes = [vp, vp, vp, vp, vp, C.c_int, C.c_int, vp, vp, vp, vp]
     L.orbm_match_batch_device.argtypes = [vp, vp, vp, vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_float, C.c_int, vp, vp, vp]
+    L.orbm_grid_build.argtypes = [vp, vp, C.c_int, C.c_float, C.c_float, C.c_float, C.c_float]
+    L.orbm_features_in_area.argtypes = [vp, vp, vp, vp, vp, vp, C.c_int, vp, vp, C.c_int]
+    L.orbm_search_area_best2.argtypes = [vp, vp, vp, vp, vp, vp, vp, C.c_int, vp, vp, vp, vp, vp]
+    L.orbm_search_area_best2_device.argtypes = [vp, vp, vp, vp, vp, vp, vp, C.c_int, vp, vp, vp, vp, vp, vp]
     L.orbm_rot_filter.argtypes = [vp, vp, vp, C.c_int]
     L.orbm_three_maxima.argtypes = [vp, C.c_int, vp]
     L.orbm_last_error.restype = C.c_char_p
     for name in ("orbm_create", "orbm_distance", "orbm_best2", "orbm_distances", "orbm_best2_batch_device",
-                 "orbm_match_batch_device", "orbm_rot_filter", "orbm_three_maxima"):
+                 "orbm_match_batch_device", "orbm_rot_filter", "orbm_three_maxima", "orbm_grid_build",
+                 "orbm_features_in_area", "orbm_search_area_best2", "orbm_search_area_best2_device"):
         getattr(L, name).restype = C.c_int
 
 
@@ -312,3 +317,42 @@ class ORBmatcher:
         th = self.TH_LOW if th is None else th
         _mchk(self.L.orbm_match_batch_device(self.h, d_q, d_kq, d_nq, d_t, d_kt, d_nt, cap, nbatch, th,
                                              self.mfNNratio, int(self.mbCheckOrientation), d_match12, d_nmatches, stream))
+
+    # ---- N1: Frame grid (src/Frame.cc:230-245, 327-392) ----
+    def grid_build(self, kps_un, min_x, max_x, min_y, max_y):
+        """Frame::AssignFeaturesToGrid for mvKeysUn with the image bounds mnMinX..mnMaxY."""
+        kps_un = np.ascontiguousarray(kps_un, KP_DTYPE)
+        self._grid_n = len(kps_un)
+        _mchk(self.L.orbm_grid_build(self.h, _p(kps_un), len(kps_un), min_x, max_x, min_y, max_y))
+
+    @staticmethod
+    def _windows(x, y, r, min_level, max_level):
+        x = np.ascontiguousarray(x, np.float32); y = np.ascontiguousarray(y, np.float32)
+        r = np.broadcast_to(np.asarray(r, np.float32), x.shape).copy()
+        mn = np.broadcast_to(np.asarray(min_level, np.int32), x.shape).copy()
+        mx = np.broadcast_to(np.asarray(max_level, np.int32), x.shape).copy()
+        return x, y, r, mn, mx
+
+    def GetFeaturesInArea(self, x, y, r, minLevel=-1, maxLevel=-1, cap=None):
+        """Frame::GetFeaturesInArea for arrays of windows -> (cand_off[nq+1], cand_idx) in reference order."""
+        x, y, r, mn, mx = self._windows(x, y, r, minLevel, maxLevel)
+        nq = len(x)
+        cap = cap or max(1, nq * max(getattr(self, "_grid_n", 0), 1))
+        cap = min(cap, 1 << 22)
+        off = np.zeros(nq + 1, np.int32); idx = np.zeros(cap, np.int32)
+        n = self.L.orbm_features_in_area(self.h, _p(x), _p(y), _p(r), _p(mn), _p(mx), nq, _p(off), _p(idx), cap)
+        if n < 0:
+            _mchk(n)
+        return off, idx[:n].copy()
+
+    def search_area_best2(self, qdesc, x, y, r, minLevel, maxLevel, train_desc, skip=None):
+        qdesc = np.ascontiguousarray(qdesc, np.uint8).reshape(-1, 32)
+        train_desc = np.ascontiguousarray(train_desc, np.uint8).reshape(-1, 32)
+        x, y, r, mn, mx = self._windows(x, y, r, minLevel, maxLevel)
+        nq = len(x)
+        if skip is not None:
+            skip = np.ascontiguousarray(skip, np.uint8)
+        bi, bd, sd = np.full(nq, -1, np.int32), np.full(nq, 256, np.int32), np.full(nq, 256, np.int32)
+        _mchk(self.L.orbm_search_area_best2(self.h, _p(qdesc), _p(x), _p(y), _p(r), _p(mn), _p(mx), nq, _p(train_desc), _p(skip),
+                                            _p(bi), _p(bd), _p(sd)))
+        return bi, bd, sd

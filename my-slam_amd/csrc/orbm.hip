@@ -12,13 +12,10 @@
 #include <string>
 #include <vector>
 
-#include <hip/hip_runtime.h>
-#include "../../include/orbm.h"
-
-#define M_THREADS 256
+#include "orbm_internal.h"
 
 static thread_local std::string g_merr;
-static int mfail(int code, const char *fmt, ...)
+int mfail(int code, const char *fmt, ...)
 {
     char buf[512];
     va_list ap;
@@ -28,25 +25,7 @@ static int mfail(int code, const char *fmt, ...)
     g_merr = buf;
     return code;
 }
-#define MHIPCHK(expr)                                                                            \
-    do {                                                                                         \
-        hipError_t e_ = (expr);                                                                  \
-        if (e_ != hipSuccess) return mfail(ORBX_E_HIP, "%s: %s", #expr, hipGetErrorString(e_)); \
-    } while (0)
 extern "C" const char *orbm_last_error(void) { return g_merr.c_str(); }
-
-__device__ __forceinline__ int hamming256(const uint4 &a0, const uint4 &a1, const uint4 &b0, const uint4 &b1)
-{
-    int d = __popc(a0.x ^ b0.x);
-    d += __popc(a0.y ^ b0.y);
-    d += __popc(a0.z ^ b0.z);
-    d += __popc(a0.w ^ b0.w);
-    d += __popc(a1.x ^ b1.x);
-    d += __popc(a1.y ^ b1.y);
-    d += __popc(a1.z ^ b1.z);
-    d += __popc(a1.w ^ b1.w);
-    return d;
-}
 
 // ---- dense best/second-best: one query per thread (8 VGPRs); the train range of a workgroup is
 // staged through double-buffered 4 KiB LDS tiles and read back as wave-uniform broadcasts
@@ -314,14 +293,6 @@ __global__ __launch_bounds__(ACC_THREADS) void k_accept_rot(
 // -------------------------------------------------------------------------------------------------
 // C ABI
 // -------------------------------------------------------------------------------------------------
-struct orbm_matcher {
-    int device = 0, max_q = 0, max_t = 0, max_pairs = 0;
-    hipStream_t stream = nullptr;
-    uint8_t *d_q = nullptr, *d_t = nullptr;
-    int32_t *d_off = nullptr, *d_idx = nullptr, *d_out = nullptr;   // d_out: max(3*max_q, max_pairs) ints
-    uint2 *d_part = nullptr; size_t part_elems = 0;                  // train-split partials (lazy)
-};
-
 extern "C" int orbm_distance(const uint8_t a[32], const uint8_t b[32])
 {
     int dist = 0;
@@ -340,6 +311,8 @@ extern "C" void orbm_destroy(orbm_matcher *m)
     (void)hipSetDevice(m->device);
     (void)hipFree(m->d_q); (void)hipFree(m->d_t); (void)hipFree(m->d_off); (void)hipFree(m->d_idx);
     (void)hipFree(m->d_out); (void)hipFree(m->d_part);
+    (void)hipFree(m->grid.kx); (void)hipFree(m->grid.ky); (void)hipFree(m->grid.koct); (void)hipFree(m->grid.cell_start);
+    (void)hipFree(m->grid.items); (void)hipFree(m->grid.cell_of); (void)hipFree(m->d_qf); (void)hipFree(m->d_qi); (void)hipFree(m->d_skip);
     if (m->stream) (void)hipStreamDestroy(m->stream);
     delete m;
 }

@@ -1,0 +1,360 @@
+// orbm_grid.hip -- the 64x48 Frame grid and windowed searches on gfx950.
+// Reference (WChen09/My-SLAM): src/Frame.cc:230-245 AssignFeaturesToGrid, :382-392 PosInGrid,
+// :327-380 GetFeaturesInArea; consumers: ORBmatcher::SearchByProjection (src/ORBmatcher.cc:1397-1430),
+// SearchForInitialization (:425-457).  The window maths is fp32 exactly as written there (no
+// contraction: __f*_rn); candidate ORDER is the reference's (cell column, cell row, push_back order),
+// because "first candidate wins a tie" depends on it.
+#include <algorithm>
+#include <vector>
+
+#include "orbm_internal.h"
+
+// -------------------------------------------------------------------------------------------------
+// k_grid_build: one 1024-thread workgroup.  Count per cell (LDS atomics) -> scan -> scatter -> each
+// cell's short list is sorted ascending, which restores push_back order (keypoint index order).
+// -------------------------------------------------------------------------------------------------
+#define G_THREADS 1024
+__global__ __launch_bounds__(G_THREADS) void k_grid_build(OrbmGrid g, const orbx_keypoint *__restrict__ kps)
+{
+    __shared__ int cnt[ORBM_GRID_CELLS];
+    __shared__ int start[ORBM_GRID_CELLS + 1];
+    __shared__ int wsum[G_THREADS / 64 + 1];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    for (int c = tid; c < ORBM_GRID_CELLS; c += G_THREADS) cnt[c] = 0;
+    __syncthreads();
+    for (int i = tid; i < g.n; i += G_THREADS) {
+        const orbx_keypoint kp = kps[i];
+        g.kx[i] = kp.x; g.ky[i] = kp.y; g.koct[i] = kp.octave;
+        const int px = (int)roundf(__fmul_rn(__fsub_rn(kp.x, g.min_x), g.inv_w));   // PosInGrid :384
+        const int py = (int)roundf(__fmul_rn(__fsub_rn(kp.y, g.min_y), g.inv_h));   // :385
+        int cell = -1;
+        if (px >= 0 && px < ORBM_GRID_COLS && py >= 0 && py < ORBM_GRID_ROWS) {
+            cell = px * ORBM_GRID_ROWS + py;
+            atomicAdd(&cnt[cell], 1);
+        }
+        g.cell_of[i] = cell;
+    }
+    __syncthreads();
+    // exclusive scan of 3072 counts: 3 per thread
+    const int c0 = tid * 3;
+    const int a = cnt[c0], b = cnt[c0 + 1], c = cnt[c0 + 2];
+    int inc = a + b + c;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const int t = __shfl_up(inc, o);
+        if (lane >= o) inc += t;
+    }
+    if (lane == 63) wsum[wave] = inc;
+    __syncthreads();
+    if (wave == 0) {
+        int w = lane < G_THREADS / 64 ? wsum[lane] : 0, wi = w;
+#pragma unroll
+        for (int o = 1; o < G_THREADS / 64; o <<= 1) {
+            const int t = __shfl_up(wi, o);
+            if (lane >= o) wi += t;
+        }
+        if (lane < G_THREADS / 64) wsum[lane] = wi - w;
+        if (lane == G_THREADS / 64 - 1) wsum[G_THREADS / 64] = wi;
+    }
+    __syncthreads();
+    const int ex = wsum[wave] + inc - (a + b + c);
+    start[c0] = ex; start[c0 + 1] = ex + a; start[c0 + 2] = ex + a + b;
+    if (tid == 0) start[ORBM_GRID_CELLS] = wsum[G_THREADS / 64];
+    cnt[c0] = 0; cnt[c0 + 1] = 0; cnt[c0 + 2] = 0;
+    __syncthreads();
+    for (int i = tid; i <= ORBM_GRID_CELLS; i += G_THREADS) g.cell_start[i] = start[i];
+    for (int i = tid; i < g.n; i += G_THREADS) {
+        const int cell = g.cell_of[i];
+        if (cell >= 0) g.items[start[cell] + atomicAdd(&cnt[cell], 1)] = i;
+    }
+    __syncthreads();
+    __threadfence_block();
+    for (int cl = tid; cl < ORBM_GRID_CELLS; cl += G_THREADS) {     // insertion sort of a short list
+        const int s = start[cl], e = start[cl + 1];
+        for (int i = s + 1; i < e; i++) {
+            const int v = g.items[i];
+            int j = i - 1;
+            while (j >= s && g.items[j] > v) { g.items[j + 1] = g.items[j]; j--; }
+            g.items[j + 1] = v;
+        }
+    }
+}
+
+// cell range of a window, src/Frame.cc:332-346.  Returns false when the window misses the grid.
+__device__ __forceinline__ bool window_cells(const OrbmGrid &g, float x, float y, float r,
+                                             int &cx0, int &cx1, int &cy0, int &cy1)
+{
+    cx0 = max(0, (int)floorf(__fmul_rn(__fsub_rn(__fsub_rn(x, g.min_x), r), g.inv_w)));
+    if (cx0 >= ORBM_GRID_COLS) return false;
+    cx1 = min(ORBM_GRID_COLS - 1, (int)ceilf(__fmul_rn(__fadd_rn(__fsub_rn(x, g.min_x), r), g.inv_w)));
+    if (cx1 < 0) return false;
+    cy0 = max(0, (int)floorf(__fmul_rn(__fsub_rn(__fsub_rn(y, g.min_y), r), g.inv_h)));
+    if (cy0 >= ORBM_GRID_ROWS) return false;
+    cy1 = min(ORBM_GRID_ROWS - 1, (int)ceilf(__fmul_rn(__fadd_rn(__fsub_rn(y, g.min_y), r), g.inv_h)));
+    if (cy1 < 0) return false;
+    return true;
+}
+
+__device__ __forceinline__ bool in_window(const OrbmGrid &g, int i, float x, float y, float r, int minl, int maxl)
+{
+    if ((minl > 0) || (maxl >= 0)) {                       // bCheckLevels :348
+        const int oct = g.koct[i];
+        if (oct < minl) return false;
+        if (maxl >= 0 && oct > maxl) return false;
+    }
+    return fabsf(__fsub_rn(g.kx[i], x)) < r && fabsf(__fsub_rn(g.ky[i], y)) < r;   // :368-372
+}
+
+// one wave per window; MODE 0 = count, 1 = write the list at off[q] in the reference's order
+template <int MODE>
+__global__ __launch_bounds__(M_THREADS) void k_area_list(OrbmGrid g, const float *__restrict__ qx, const float *__restrict__ qy,
+                                                        const float *__restrict__ qr, const int32_t *__restrict__ minl,
+                                                        const int32_t *__restrict__ maxl, int nq,
+                                                        int32_t *__restrict__ counts, const int32_t *__restrict__ off,
+                                                        int32_t *__restrict__ out)
+{
+    const int lane = threadIdx.x & 63;
+    const int q = blockIdx.x * (M_THREADS / 64) + (threadIdx.x >> 6);
+    if (q >= nq) return;
+    const float x = qx[q], y = qy[q], r = qr[q];
+    const int mn = minl[q], mx = maxl[q];
+    int n = 0, cx0, cx1, cy0, cy1;
+    if (window_cells(g, x, y, r, cx0, cx1, cy0, cy1)) {
+        const int base = MODE == 1 ? off[q] : 0;
+        for (int ix = cx0; ix <= cx1; ix++) {              // a cell column is one contiguous item range
+            const int s = g.cell_start[ix * ORBM_GRID_ROWS + cy0], e = g.cell_start[ix * ORBM_GRID_ROWS + cy1 + 1];
+            for (int j0 = s; j0 < e; j0 += 64) {
+                const int j = j0 + lane;
+                int i = -1;
+                bool ok = false;
+                if (j < e) { i = g.items[j]; ok = in_window(g, i, x, y, r, mn, mx); }
+                const unsigned long long m = __ballot(ok);
+                if (MODE == 1 && ok) out[base + n + __popcll(m & ((1ull << lane) - 1ull))] = i;
+                n += __popcll(m);
+            }
+        }
+    }
+    if (MODE == 0 && lane == 0) counts[q] = n;
+}
+
+// fused window query + best / second-best (strict '<': first candidate wins ties, a tie with the best
+// becomes the second best).  Key = distance << 22 | position in the reference's candidate order.
+__global__ __launch_bounds__(M_THREADS) void k_search_area(OrbmGrid g, const uint8_t *__restrict__ qdesc,
+                                                          const float *__restrict__ qx, const float *__restrict__ qy,
+                                                          const float *__restrict__ qr, const int32_t *__restrict__ minl,
+                                                          const int32_t *__restrict__ maxl, int nq,
+                                                          const uint8_t *__restrict__ tdesc, const uint8_t *__restrict__ skip,
+                                                          int32_t *__restrict__ best_idx, int32_t *__restrict__ best_d,
+                                                          int32_t *__restrict__ second_d)
+{
+    const int lane = threadIdx.x & 63;
+    const int q = blockIdx.x * (M_THREADS / 64) + (threadIdx.x >> 6);
+    if (q >= nq) return;
+    const float x = qx[q], y = qy[q], r = qr[q];
+    const int mn = minl[q], mx = maxl[q];
+    const uint4 *Q = reinterpret_cast<const uint4 *>(qdesc) + 2 * (long long)q;
+    const uint4 q0 = Q[0], q1 = Q[1];
+    uint32_t bp = (256u << 22) | 0x3FFFFFu;
+    int s2 = 256, bidx = -1, n = 0;
+    int cx0, cx1, cy0, cy1;
+    if (window_cells(g, x, y, r, cx0, cx1, cy0, cy1)) {
+        for (int ix = cx0; ix <= cx1; ix++) {
+            const int s = g.cell_start[ix * ORBM_GRID_ROWS + cy0], e = g.cell_start[ix * ORBM_GRID_ROWS + cy1 + 1];
+            for (int j0 = s; j0 < e; j0 += 64) {
+                const int j = j0 + lane;
+                int i = -1;
+                bool ok = false;
+                if (j < e) {
+                    i = g.items[j];
+                    ok = in_window(g, i, x, y, r, mn, mx) && !(skip && skip[i]);
+                }
+                const unsigned long long m = __ballot(ok);
+                if (ok) {
+                    const uint4 *Tj = reinterpret_cast<const uint4 *>(tdesc) + 2 * (long long)i;
+                    const int d = hamming256(q0, q1, Tj[0], Tj[1]);
+                    const uint32_t p = ((uint32_t)d << 22) | (uint32_t)min(n + __popcll(m & ((1ull << lane) - 1ull)), 0x3FFFFF);
+                    if (p < bp) { s2 = (int)(bp >> 22); bp = p; bidx = i; }
+                    else if (d < s2) s2 = d;
+                }
+                n += __popcll(m);
+            }
+        }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const uint32_t op = __shfl_xor(bp, o);
+        const int os = __shfl_xor(s2, o);
+        const int oi = __shfl_xor(bidx, o);
+        const int loser = (int)(max(bp, op) >> 22);
+        if (op < bp) bidx = oi;
+        bp = min(bp, op);
+        s2 = min(min(s2, os), loser);
+    }
+    if (lane == 0) {
+        const int d = (int)(bp >> 22);
+        best_d[q] = d;
+        second_d[q] = s2;
+        best_idx[q] = d < 256 ? bidx : -1;
+    }
+}
+
+// -------------------------------------------------------------------------------------------------
+// C ABI
+// -------------------------------------------------------------------------------------------------
+static int ensure_grid(orbm_matcher *m)
+{
+    if (m->grid.cell_start) return ORBX_OK;
+    const size_t n = (size_t)m->max_t;
+    MHIPCHK(hipMalloc((void **)&m->grid.kx, n * 4));
+    MHIPCHK(hipMalloc((void **)&m->grid.ky, n * 4));
+    MHIPCHK(hipMalloc((void **)&m->grid.koct, n * 4));
+    MHIPCHK(hipMalloc((void **)&m->grid.items, n * 4));
+    MHIPCHK(hipMalloc((void **)&m->grid.cell_of, n * 4));
+    MHIPCHK(hipMalloc((void **)&m->grid.cell_start, (ORBM_GRID_CELLS + 1) * 4));
+    return ORBX_OK;
+}
+
+static int ensure_query_staging(orbm_matcher *m, size_t nq)
+{
+    if (nq <= m->qf_elems) return ORBX_OK;
+    MHIPCHK(hipDeviceSynchronize());
+    (void)hipFree(m->d_qf); (void)hipFree(m->d_qi);
+    m->d_qf = nullptr; m->d_qi = nullptr; m->qf_elems = 0;
+    MHIPCHK(hipMalloc((void **)&m->d_qf, nq * 3 * sizeof(float)));
+    MHIPCHK(hipMalloc((void **)&m->d_qi, nq * 4 * sizeof(int32_t)));    // min_level, max_level, counts, offsets
+    m->qf_elems = nq;
+    return ORBX_OK;
+}
+
+extern "C" int orbm_grid_build(orbm_matcher *m, const orbx_keypoint *kps_un, int n,
+                               float min_x, float max_x, float min_y, float max_y)
+{
+    if (!m) return mfail(ORBX_E_INVALID, "NULL handle");
+    if (n < 0 || n > m->max_t) return mfail(ORBX_E_CAPACITY, "n=%d keypoints, matcher sized for %d", n, m->max_t);
+    if (n > 0 && !kps_un) return mfail(ORBX_E_INVALID, "NULL keypoints");
+    if (!(max_x > min_x) || !(max_y > min_y)) return mfail(ORBX_E_INVALID, "empty image bounds");
+    MHIPCHK(hipSetDevice(m->device));
+    int rc = ensure_grid(m);
+    if (rc != ORBX_OK) return rc;
+    m->grid.min_x = min_x; m->grid.min_y = min_y;
+    m->grid.inv_w = (float)ORBM_GRID_COLS / (max_x - min_x);     // src/Frame.cc:212
+    m->grid.inv_h = (float)ORBM_GRID_ROWS / (max_y - min_y);     // :213
+    m->grid.n = n;
+    hipStream_t s = m->stream;
+    orbx_keypoint *d_kps = reinterpret_cast<orbx_keypoint *>(m->d_out);   // staging: 3*max_q ints >= 7*n? checked below
+    const size_t need = (size_t)n * sizeof(orbx_keypoint);
+    const size_t have = std::max<size_t>((size_t)3 * m->max_q, (size_t)m->max_pairs) * 4;
+    void *tmp = nullptr;
+    if (need > have) { MHIPCHK(hipMalloc(&tmp, need)); d_kps = reinterpret_cast<orbx_keypoint *>(tmp); }
+    if (n > 0) MHIPCHK(hipMemcpyAsync(d_kps, kps_un, need, hipMemcpyHostToDevice, s));
+    hipLaunchKernelGGL(k_grid_build, dim3(1), dim3(G_THREADS), 0, s, m->grid, d_kps);
+    MHIPCHK(hipGetLastError());
+    MHIPCHK(hipStreamSynchronize(s));
+    if (tmp) (void)hipFree(tmp);
+    m->grid_ok = true;
+    return ORBX_OK;
+}
+
+static int upload_windows(orbm_matcher *m, const float *x, const float *y, const float *r, const int32_t *mn,
+                          const int32_t *mx, int nq, hipStream_t s)
+{
+    int rc = ensure_query_staging(m, (size_t)nq);
+    if (rc != ORBX_OK) return rc;
+    MHIPCHK(hipMemcpyAsync(m->d_qf, x, (size_t)nq * 4, hipMemcpyHostToDevice, s));
+    MHIPCHK(hipMemcpyAsync(m->d_qf + m->qf_elems, y, (size_t)nq * 4, hipMemcpyHostToDevice, s));
+    MHIPCHK(hipMemcpyAsync(m->d_qf + 2 * m->qf_elems, r, (size_t)nq * 4, hipMemcpyHostToDevice, s));
+    MHIPCHK(hipMemcpyAsync(m->d_qi, mn, (size_t)nq * 4, hipMemcpyHostToDevice, s));
+    MHIPCHK(hipMemcpyAsync(m->d_qi + m->qf_elems, mx, (size_t)nq * 4, hipMemcpyHostToDevice, s));
+    return ORBX_OK;
+}
+
+extern "C" int orbm_features_in_area(orbm_matcher *m, const float *x, const float *y, const float *r,
+                                     const int32_t *min_level, const int32_t *max_level, int nq,
+                                     int32_t *cand_off, int32_t *cand_idx, int cap_idx)
+{
+    if (!m) return mfail(ORBX_E_INVALID, "NULL handle");
+    if (!m->grid_ok) return mfail(ORBX_E_INVALID, "orbm_grid_build has not been called");
+    if (nq < 0 || !cand_off) return mfail(ORBX_E_INVALID, "bad argument");
+    cand_off[0] = 0;
+    if (nq == 0) return 0;
+    if (!x || !y || !r || !min_level || !max_level) return mfail(ORBX_E_INVALID, "NULL window array");
+    MHIPCHK(hipSetDevice(m->device));
+    hipStream_t s = m->stream;
+    int rc = upload_windows(m, x, y, r, min_level, max_level, nq, s);
+    if (rc != ORBX_OK) return rc;
+    const size_t Q = m->qf_elems;
+    int32_t *d_cnt = m->d_qi + 2 * Q, *d_off = m->d_qi + 3 * Q;
+    const dim3 grid((nq + 3) / 4);
+    hipLaunchKernelGGL(k_area_list<0>, grid, dim3(M_THREADS), 0, s, m->grid, m->d_qf, m->d_qf + Q, m->d_qf + 2 * Q, m->d_qi, m->d_qi + Q,
+                       nq, d_cnt, (const int32_t *)nullptr, (int32_t *)nullptr);
+    MHIPCHK(hipGetLastError());
+    std::vector<int32_t> cnt(nq);
+    MHIPCHK(hipMemcpyAsync(cnt.data(), d_cnt, (size_t)nq * 4, hipMemcpyDeviceToHost, s));
+    MHIPCHK(hipStreamSynchronize(s));
+    for (int i = 0; i < nq; i++) cand_off[i + 1] = cand_off[i] + cnt[i];
+    const int total = cand_off[nq];
+    if (total > cap_idx) return mfail(ORBX_E_CAPACITY, "%d candidates, caller capacity %d", total, cap_idx);
+    if (total == 0) return 0;
+    if (!cand_idx) return mfail(ORBX_E_INVALID, "cand_idx is NULL");
+    if (total > m->max_pairs) return mfail(ORBX_E_CAPACITY, "%d candidates, matcher sized for %d pairs", total, m->max_pairs);
+    MHIPCHK(hipMemcpyAsync(d_off, cand_off, (size_t)nq * 4, hipMemcpyHostToDevice, s));
+    hipLaunchKernelGGL(k_area_list<1>, grid, dim3(M_THREADS), 0, s, m->grid, m->d_qf, m->d_qf + Q, m->d_qf + 2 * Q, m->d_qi, m->d_qi + Q,
+                       nq, (int32_t *)nullptr, d_off, m->d_idx);
+    MHIPCHK(hipGetLastError());
+    MHIPCHK(hipMemcpyAsync(cand_idx, m->d_idx, (size_t)total * 4, hipMemcpyDeviceToHost, s));
+    MHIPCHK(hipStreamSynchronize(s));
+    return total;
+}
+
+extern "C" int orbm_search_area_best2_device(orbm_matcher *m, const uint8_t *d_qdesc, const float *d_x, const float *d_y,
+                                             const float *d_r, const int32_t *d_min_level, const int32_t *d_max_level, int nq,
+                                             const uint8_t *d_train_desc, const uint8_t *d_skip,
+                                             int32_t *d_best_idx, int32_t *d_best_d, int32_t *d_second_d, void *hip_stream)
+{
+    if (!m) return mfail(ORBX_E_INVALID, "NULL handle");
+    if (!m->grid_ok) return mfail(ORBX_E_INVALID, "orbm_grid_build has not been called");
+    if (nq <= 0) return nq == 0 ? ORBX_OK : mfail(ORBX_E_INVALID, "nq < 0");
+    if (!d_qdesc || !d_x || !d_y || !d_r || !d_min_level || !d_max_level || !d_train_desc || !d_best_idx || !d_best_d || !d_second_d)
+        return mfail(ORBX_E_INVALID, "NULL device pointer");
+    MHIPCHK(hipSetDevice(m->device));
+    hipStream_t s = hip_stream ? (hipStream_t)hip_stream : m->stream;
+    hipLaunchKernelGGL(k_search_area, dim3((nq + 3) / 4), dim3(M_THREADS), 0, s, m->grid, d_qdesc, d_x, d_y, d_r, d_min_level,
+                       d_max_level, nq, d_train_desc, d_skip, d_best_idx, d_best_d, d_second_d);
+    MHIPCHK(hipGetLastError());
+    return ORBX_OK;
+}
+
+extern "C" int orbm_search_area_best2(orbm_matcher *m, const uint8_t *qdesc, const float *x, const float *y, const float *r,
+                                      const int32_t *min_level, const int32_t *max_level, int nq,
+                                      const uint8_t *train_desc, const uint8_t *skip,
+                                      int32_t *best_idx, int32_t *best_d, int32_t *second_d)
+{
+    if (!m) return mfail(ORBX_E_INVALID, "NULL handle");
+    if (!m->grid_ok) return mfail(ORBX_E_INVALID, "orbm_grid_build has not been called");
+    if (nq < 0 || nq > m->max_q) return mfail(ORBX_E_CAPACITY, "nq=%d, matcher sized for %d", nq, m->max_q);
+    if (nq == 0) return ORBX_OK;
+    if (!qdesc || !x || !y || !r || !min_level || !max_level || !best_idx || !best_d || !second_d || (m->grid.n > 0 && !train_desc))
+        return mfail(ORBX_E_INVALID, "NULL buffer");
+    MHIPCHK(hipSetDevice(m->device));
+    hipStream_t s = m->stream;
+    int rc = upload_windows(m, x, y, r, min_level, max_level, nq, s);
+    if (rc != ORBX_OK) return rc;
+    const size_t Q = m->qf_elems;
+    MHIPCHK(hipMemcpyAsync(m->d_q, qdesc, (size_t)nq * 32, hipMemcpyHostToDevice, s));
+    if (m->grid.n > 0) MHIPCHK(hipMemcpyAsync(m->d_t, train_desc, (size_t)m->grid.n * 32, hipMemcpyHostToDevice, s));
+    const uint8_t *d_skip = nullptr;
+    if (skip && m->grid.n > 0) {
+        if (!m->d_skip) MHIPCHK(hipMalloc((void **)&m->d_skip, (size_t)m->max_t));
+        MHIPCHK(hipMemcpyAsync(m->d_skip, skip, (size_t)m->grid.n, hipMemcpyHostToDevice, s));
+        d_skip = m->d_skip;
+    }
+    int32_t *o_bi = m->d_out, *o_bd = m->d_out + nq, *o_sd = m->d_out + 2 * (size_t)nq;
+    rc = orbm_search_area_best2_device(m, m->d_q, m->d_qf, m->d_qf + Q, m->d_qf + 2 * Q, m->d_qi, m->d_qi + Q, nq, m->d_t, d_skip,
+                                       o_bi, o_bd, o_sd, s);
+    if (rc != ORBX_OK) return rc;
+    MHIPCHK(hipMemcpyAsync(best_idx, o_bi, (size_t)nq * 4, hipMemcpyDeviceToHost, s));
+    MHIPCHK(hipMemcpyAsync(best_d, o_bd, (size_t)nq * 4, hipMemcpyDeviceToHost, s));
+    MHIPCHK(hipMemcpyAsync(second_d, o_sd, (size_t)nq * 4, hipMemcpyDeviceToHost, s));
+    MHIPCHK(hipStreamSynchronize(s));
+    return ORBX_OK;
+}

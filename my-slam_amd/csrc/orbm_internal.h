@@ -1,0 +1,54 @@
+// orbm_internal.h -- shared by orbm.hip and orbm_grid.hip
+#pragma once
+#include <cstdarg>
+#include <cstdio>
+#include <string>
+#include <hip/hip_runtime.h>
+#include "../../include/orbm.h"
+
+#define M_THREADS 256
+
+int mfail(int code, const char *fmt, ...);
+#define MHIPCHK(expr)                                                                            \
+    do {                                                                                         \
+        hipError_t e_ = (expr);                                                                  \
+        if (e_ != hipSuccess) return mfail(ORBX_E_HIP, "%s: %s", #expr, hipGetErrorString(e_)); \
+    } while (0)
+
+__device__ __forceinline__ int hamming256(const uint4 &a0, const uint4 &a1, const uint4 &b0, const uint4 &b1)
+{
+    int d = __popc(a0.x ^ b0.x);
+    d += __popc(a0.y ^ b0.y);
+    d += __popc(a0.z ^ b0.z);
+    d += __popc(a0.w ^ b0.w);
+    d += __popc(a1.x ^ b1.x);
+    d += __popc(a1.y ^ b1.y);
+    d += __popc(a1.z ^ b1.z);
+    d += __popc(a1.w ^ b1.w);
+    return d;
+}
+
+#define ORBM_GRID_COLS 64   // FRAME_GRID_COLS, include/Frame.h:38
+#define ORBM_GRID_ROWS 48   // FRAME_GRID_ROWS, include/Frame.h:37
+#define ORBM_GRID_CELLS (ORBM_GRID_COLS * ORBM_GRID_ROWS)
+
+struct OrbmGrid {               // device-resident Frame grid of the train frame
+    float min_x, min_y, inv_w, inv_h;
+    int n;
+    float *kx, *ky; int32_t *koct;      // SoA copy of the undistorted keypoints
+    int32_t *cell_start;                // [ORBM_GRID_CELLS + 1]
+    int32_t *items;                     // [n] keypoint indices, push_back order inside a cell
+    int32_t *cell_of;                   // [n] scratch
+};
+
+struct orbm_matcher {
+    int device = 0, max_q = 0, max_t = 0, max_pairs = 0;
+    hipStream_t stream = nullptr;
+    uint8_t *d_q = nullptr, *d_t = nullptr;
+    int32_t *d_off = nullptr, *d_idx = nullptr, *d_out = nullptr;   // d_out: max(3*max_q, max_pairs) ints
+    uint2 *d_part = nullptr; size_t part_elems = 0;                  // train-split partials (lazy)
+    OrbmGrid grid = {};  bool grid_ok = false;                       // N1: Frame grid of the last orbm_grid_build
+    float *d_qf = nullptr; int32_t *d_qi = nullptr; uint8_t *d_skip = nullptr;   // window-query staging (lazy)
+    size_t qf_elems = 0;
+};
+

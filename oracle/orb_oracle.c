@@ -973,3 +973,90 @@ int oro_match_dense(const uint8_t *q, const float *angle_q, int nq,
     if (check_ori) nmatches = oro_rot_filter(angle_q, angle_t, match12, nq);
     return nmatches;
 }
+
+/* ------------------------------------------------------------------------------------------------
+ * N1: Frame::AssignFeaturesToGrid / PosInGrid / GetFeaturesInArea (src/Frame.cc:230-245, 327-392)
+ * ---------------------------------------------------------------------------------------------- */
+static int pos_in_grid(const oro_grid *g, const oro_keypoint *kp, int *px, int *py)
+{
+    *px = (int)roundf((kp->x - g->min_x) * g->inv_w);   /* :384 */
+    *py = (int)roundf((kp->y - g->min_y) * g->inv_h);   /* :385 */
+    if (*px < 0 || *px >= ORO_GRID_COLS || *py < 0 || *py >= ORO_GRID_ROWS) return 0;
+    return 1;
+}
+
+void oro_grid_build(oro_grid *g, const oro_keypoint *kps_un, int n, float min_x, float max_x, float min_y, float max_y, int *items)
+{
+    g->min_x = min_x; g->max_x = max_x; g->min_y = min_y; g->max_y = max_y;
+    g->inv_w = (float)ORO_GRID_COLS / (max_x - min_x);   /* :212 */
+    g->inv_h = (float)ORO_GRID_ROWS / (max_y - min_y);   /* :213 */
+    g->n = n; g->items = items;
+    const int NC = ORO_GRID_COLS * ORO_GRID_ROWS;
+    int *cnt = (int *)calloc((size_t)NC + 1, sizeof(int));
+    int *cell = (int *)malloc(sizeof(int) * (size_t)(n ? n : 1));
+    for (int i = 0; i < n; i++) {
+        int px, py;
+        cell[i] = pos_in_grid(g, &kps_un[i], &px, &py) ? px * ORO_GRID_ROWS + py : -1;
+        if (cell[i] >= 0) cnt[cell[i]]++;
+    }
+    g->cell_start[0] = 0;
+    for (int c = 0; c < NC; c++) g->cell_start[c + 1] = g->cell_start[c] + cnt[c];
+    memset(cnt, 0, sizeof(int) * (size_t)NC);
+    for (int i = 0; i < n; i++)      /* push_back in keypoint order (:237-244) */
+        if (cell[i] >= 0) items[g->cell_start[cell[i]] + cnt[cell[i]]++] = i;
+    free(cnt); free(cell);
+}
+
+int oro_features_in_area(const oro_grid *g, const oro_keypoint *kps_un, float x, float y, float r,
+                         int minLevel, int maxLevel, int32_t *out, int cap)
+{
+    int n = 0;
+    const int nMinCellX = imax(0, (int)floorf((x - g->min_x - r) * g->inv_w));
+    if (nMinCellX >= ORO_GRID_COLS) return 0;
+    const int nMaxCellX = imin(ORO_GRID_COLS - 1, (int)ceilf((x - g->min_x + r) * g->inv_w));
+    if (nMaxCellX < 0) return 0;
+    const int nMinCellY = imax(0, (int)floorf((y - g->min_y - r) * g->inv_h));
+    if (nMinCellY >= ORO_GRID_ROWS) return 0;
+    const int nMaxCellY = imin(ORO_GRID_ROWS - 1, (int)ceilf((y - g->min_y + r) * g->inv_h));
+    if (nMaxCellY < 0) return 0;
+    const int bCheckLevels = (minLevel > 0) || (maxLevel >= 0);
+    for (int ix = nMinCellX; ix <= nMaxCellX; ix++) {
+        for (int iy = nMinCellY; iy <= nMaxCellY; iy++) {
+            const int c = ix * ORO_GRID_ROWS + iy;
+            for (int j = g->cell_start[c]; j < g->cell_start[c + 1]; j++) {
+                const oro_keypoint *kpUn = &kps_un[g->items[j]];
+                if (bCheckLevels) {
+                    if (kpUn->octave < minLevel) continue;
+                    if (maxLevel >= 0 && kpUn->octave > maxLevel) continue;
+                }
+                const float distx = kpUn->x - x, disty = kpUn->y - y;
+                if (fabsf(distx) < r && fabsf(disty) < r) {
+                    if (n >= cap) return -1;
+                    out[n++] = g->items[j];
+                }
+            }
+        }
+    }
+    return n;
+}
+
+void oro_search_area_best2(const oro_grid *g, const oro_keypoint *kps_un, const uint8_t *train_desc, const uint8_t *skip,
+                           const uint8_t *qdesc, const float *x, const float *y, const float *r,
+                           const int32_t *min_level, const int32_t *max_level, int nq,
+                           int32_t *best_idx, int32_t *best_d, int32_t *second_d)
+{
+    int32_t *idx = (int32_t *)malloc(sizeof(int32_t) * (size_t)(g->n ? g->n : 1));
+    for (int i = 0; i < nq; i++) {
+        int nc = oro_features_in_area(g, kps_un, x[i], y[i], r[i], min_level[i], max_level[i], idx, g->n);
+        int bestDist = 256, bestDist2 = 256, bestIdx = -1;
+        for (int c = 0; c < nc; c++) {
+            const int i2 = idx[c];
+            if (skip && skip[i2]) continue;
+            const int dist = oro_descriptor_distance(qdesc + (size_t)i * 32, train_desc + (size_t)i2 * 32);
+            if (dist < bestDist) { bestDist2 = bestDist; bestDist = dist; bestIdx = i2; }
+            else if (dist < bestDist2) { bestDist2 = dist; }
+        }
+        best_idx[i] = bestIdx; best_d[i] = bestDist; second_d[i] = bestDist2;
+    }
+    free(idx);
+}

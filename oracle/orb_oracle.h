@@ -131,6 +131,28 @@ int oro_match_dense(const uint8_t *q, const float *angle_q, int nq,
                     const uint8_t *t, const float *angle_t, int nt,
                     int th, float nnratio, int check_ori, int32_t *match12);
 
+/* ---- N1: Frame grid (src/Frame.cc:230-245, 327-392) ---- */
+#define ORO_GRID_COLS 64   /* include/Frame.h:38 */
+#define ORO_GRID_ROWS 48   /* include/Frame.h:37 */
+typedef struct {
+    float min_x, max_x, min_y, max_y;       /* mnMinX, mnMaxX, mnMinY, mnMaxY (Frame::ComputeImageBounds) */
+    float inv_w, inv_h;                     /* mfGridElementWidthInv / HeightInv (src/Frame.cc:212-213) */
+    int n;                                  /* keypoints */
+    int cell_start[ORO_GRID_COLS * ORO_GRID_ROWS + 1];   /* CSR over cells, cell = ix*48 + iy */
+    int *items;                             /* keypoint indices, push_back order inside a cell */
+} oro_grid;
+/* AssignFeaturesToGrid + PosInGrid; items must hold n ints */
+void oro_grid_build(oro_grid *g, const oro_keypoint *kps_un, int n, float min_x, float max_x, float min_y, float max_y, int *items);
+/* GetFeaturesInArea: returns the count written to out (reference order), -1 if cap is too small */
+int oro_features_in_area(const oro_grid *g, const oro_keypoint *kps_un, float x, float y, float r,
+                         int min_level, int max_level, int32_t *out, int cap);
+/* window query + best/second-best scan (SearchByProjection inner loop, src/ORBmatcher.cc:1397-1424, with the
+ * second-best kept as in :432-457); skip[i] != 0 drops train keypoint i (the reference's `continue` predicates) */
+void oro_search_area_best2(const oro_grid *g, const oro_keypoint *kps_un, const uint8_t *train_desc, const uint8_t *skip,
+                           const uint8_t *qdesc, const float *x, const float *y, const float *r,
+                           const int32_t *min_level, const int32_t *max_level, int nq,
+                           int32_t *best_idx, int32_t *best_d, int32_t *second_d);
+
 #ifdef __cplusplus
 }
 #endif

@@ -78,6 +78,12 @@ def lib(native=False):
     L.oro_rot_bin.restype = C.c_int
     L.oro_rot_filter.argtypes = [vp, vp, vp, C.c_int]
     L.oro_rot_filter.restype = C.c_int
+    L.oro_grid_build.argtypes = [vp, vp, C.c_int, C.c_float, C.c_float, C.c_float, C.c_float, vp]
+    L.oro_grid_build.restype = None
+    L.oro_features_in_area.argtypes = [vp, vp, C.c_float, C.c_float, C.c_float, C.c_int, C.c_int, vp, C.c_int]
+    L.oro_features_in_area.restype = C.c_int
+    L.oro_search_area_best2.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, C.c_int, vp, vp, vp]
+    L.oro_search_area_best2.restype = None
     L.oro_match_dense.argtypes = [vp, vp, C.c_int, vp, vp, C.c_int, C.c_int, C.c_float, C.c_int, vp]
     L.oro_match_dense.restype = C.c_int
     if not native:
@@ -186,3 +192,37 @@ def match_dense(q, aq, t, at, th=50, nnratio=0.9, check_ori=True):
     m = np.empty(len(q), np.int32)
     n = L.oro_match_dense(_p(q), _p(aq), len(q), _p(t), _p(at), len(t), th, nnratio, int(check_ori), _p(m))
     return n, m
+
+
+class OroGrid(C.Structure):
+    _fields_ = [("min_x", C.c_float), ("max_x", C.c_float), ("min_y", C.c_float), ("max_y", C.c_float),
+                ("inv_w", C.c_float), ("inv_h", C.c_float), ("n", C.c_int),
+                ("cell_start", C.c_int * (64 * 48 + 1)), ("items", C.POINTER(C.c_int))]
+
+
+class FrameGrid:
+    """Frame::AssignFeaturesToGrid / GetFeaturesInArea on the oracle (src/Frame.cc:230-245, 327-380)."""
+
+    def __init__(self, kps_un, min_x, max_x, min_y, max_y):
+        self.L = lib()
+        self.kps = np.ascontiguousarray(kps_un, KP_DTYPE)
+        self.items = np.zeros(max(len(self.kps), 1), np.int32)
+        self.g = OroGrid()
+        self.L.oro_grid_build(C.byref(self.g), _p(self.kps), len(self.kps), min_x, max_x, min_y, max_y, _p(self.items))
+
+    def features_in_area(self, x, y, r, min_level=-1, max_level=-1):
+        out = np.zeros(max(len(self.kps), 1), np.int32)
+        n = self.L.oro_features_in_area(C.byref(self.g), _p(self.kps), x, y, r, min_level, max_level, _p(out), len(out))
+        assert n >= 0
+        return out[:n].copy()
+
+    def search_area_best2(self, qdesc, x, y, r, mn, mx, train_desc, skip=None):
+        qdesc = np.ascontiguousarray(qdesc, np.uint8); train_desc = np.ascontiguousarray(train_desc, np.uint8)
+        x = np.ascontiguousarray(x, np.float32); y = np.ascontiguousarray(y, np.float32); r = np.ascontiguousarray(r, np.float32)
+        mn = np.ascontiguousarray(mn, np.int32); mx = np.ascontiguousarray(mx, np.int32)
+        nq = len(x)
+        bi = np.empty(nq, np.int32); bd = np.empty(nq, np.int32); sd = np.empty(nq, np.int32)
+        sk = np.ascontiguousarray(skip, np.uint8) if skip is not None else None
+        self.L.oro_search_area_best2(C.byref(self.g), _p(self.kps), _p(train_desc), _p(sk) if sk is not None else None,
+                                     _p(qdesc), _p(x), _p(y), _p(r), _p(mn), _p(mx), nq, _p(bi), _p(bd), _p(sd))
+        return bi, bd, sd

@@ -1,0 +1,99 @@
+"""N1: Frame grid + GetFeaturesInArea + windowed best/second-best search.
+CPU: hand-checkable cases on the oracle restatement of src/Frame.cc:230-245, 327-392.
+GPU: HIP (through the C ABI) == oracle exactly, candidate order included."""
+import numpy as np
+import pytest
+
+import oracle_lib as O
+
+
+def _kps(pts):
+    k = np.zeros(len(pts), O.KP_DTYPE)
+    for i, (x, y, o) in enumerate(pts):
+        k[i] = (x, y, 31.0, 0.0, 50.0, o, -1)
+    return k
+
+
+def test_oracle_grid_by_hand():
+    # 640x480 image: cells are 10 x 10 px; PosInGrid uses round(), GetFeaturesInArea floor/ceil
+    k = _kps([(5, 5, 0), (14.9, 5, 0), (15.1, 5, 1), (100, 100, 2), (639, 479, 0), (634, 474, 0)])
+    g = O.FrameGrid(k, 0.0, 640.0, 0.0, 480.0)
+    cs = np.ctypeslib.as_array(g.g.cell_start)
+    cell = lambda i: int(np.searchsorted(cs, np.nonzero(g.items[:cs[-1]] == i)[0][0], side="right") - 1)
+    # PosInGrid rounds: 5 * 0.1 = 0.5 -> cell 1 (half away from zero), not floor
+    assert cell(0) == 1 * 48 + 1
+    assert cell(1) == 1 * 48 + 1 and cell(2) == 2 * 48 + 1
+    assert cs[-1] == 5                       # (639,479) -> posX = round(63.9) = 64 -> outside the grid: dropped (:388)
+    assert list(g.features_in_area(10.0, 5.0, 6.0)) == [0, 1, 2]          # |dx| < r strict
+    assert list(g.features_in_area(10.0, 5.0, 5.0)) == [1]                # 5 - 10 = -5: not < 5
+    assert list(g.features_in_area(10.0, 5.0, 6.0, 1, -1)) == [2]         # minLevel only
+    assert list(g.features_in_area(10.0, 5.0, 6.0, 0, 0)) == [0, 1]       # level window
+    assert list(g.features_in_area(-50.0, 5.0, 10.0)) == []               # window misses the grid
+    assert list(g.features_in_area(1000.0, 5.0, 10.0)) == []
+
+
+def test_oracle_area_order_is_column_major_then_index():
+    rng = np.random.default_rng(0)
+    pts = [(float(x), float(y), int(o)) for x, y, o in zip(rng.uniform(0, 640, 600), rng.uniform(0, 480, 600), rng.integers(0, 8, 600))]
+    k = _kps(pts)
+    g = O.FrameGrid(k, 0.0, 640.0, 0.0, 480.0)
+    idx = g.features_in_area(320.0, 240.0, 90.0)
+    assert len(idx) > 20
+    px = np.rint((k["x"][idx] - 0) * np.float32(64 / 640)).astype(int)
+    py = np.rint((k["y"][idx] - 0) * np.float32(48 / 480)).astype(int)
+    key = list(zip(px, py, idx))
+    assert key == sorted(key)
+    brute = [i for i in range(600) if abs(k["x"][i] - 320) < 90 and abs(k["y"][i] - 240) < 90
+             and 0 <= round(float(k["x"][i]) * 0.1) < 64 and 0 <= round(float(k["y"][i]) * 0.1) < 48]
+    assert sorted(idx.tolist()) == sorted(brute)
+
+
+@pytest.mark.gpu
+def test_hip_grid_and_area_equal_oracle(orbx, synth):
+    img0, img1 = synth.frame_pair(2, 960, 540)
+    ex = orbx.ORBextractor(2000, max_width=960, max_height=540)
+    k0, d0 = ex(img0)
+    k1, d1 = ex(img1)
+    m = orbx.ORBmatcher(0.9, True, max_queries=4096, max_train=4096, max_pairs=1 << 21)
+    m.grid_build(k1, 0.0, 960.0, 0.0, 540.0)
+    og = O.FrameGrid(k1, 0.0, 960.0, 0.0, 540.0)
+    rng = np.random.default_rng(1)
+    # windows around the previous frame's keypoints (the SearchForInitialization / SearchByProjection shape)
+    x = k0["x"] + rng.uniform(-8, 8, len(k0)).astype(np.float32)
+    y = k0["y"] + rng.uniform(-8, 8, len(k0)).astype(np.float32)
+    r = (15.0 * np.float32(1.2) ** k0["octave"]).astype(np.float32)
+    mn = np.maximum(k0["octave"] - 1, -1).astype(np.int32)
+    mx = (k0["octave"] + 1).astype(np.int32)
+    mn[::7] = -1; mx[::7] = -1                       # no level check
+    x[::50] = -500.0                                  # windows that miss the image
+    off, idx = m.GetFeaturesInArea(x, y, r, mn, mx)
+    for i in range(len(x)):
+        ref = og.features_in_area(float(x[i]), float(y[i]), float(r[i]), int(mn[i]), int(mx[i]))
+        assert np.array_equal(idx[off[i]:off[i + 1]], ref), i
+    assert off[-1] > 3000
+    # fused search == oracle, with and without a skip mask
+    skip = (rng.uniform(size=len(k1)) < 0.2).astype(np.uint8)
+    for sk in (None, skip):
+        bi, bd, sd = m.search_area_best2(d0, x, y, r, mn, mx, d1, sk)
+        obi, obd, osd = og.search_area_best2(d0, x, y, r, mn, mx, d1, sk)
+        assert np.array_equal(bd, obd) and np.array_equal(sd, osd) and np.array_equal(bi, obi)
+    # and it equals the two-step path GetFeaturesInArea -> orbm_best2 on the CSR lists
+    bi2, bd2, sd2 = m.best2(d0, d1, off, idx)
+    bi, bd, sd = m.search_area_best2(d0, x, y, r, mn, mx, d1, None)
+    assert np.array_equal(bi, bi2) and np.array_equal(bd, bd2) and np.array_equal(sd, sd2)
+
+
+@pytest.mark.gpu
+def test_hip_grid_edge_cases(orbx):
+    m = orbx.ORBmatcher(max_queries=64, max_train=64, max_pairs=4096)
+    with pytest.raises(orbx.OrbxError):
+        m.GetFeaturesInArea([1.0], [1.0], 5.0)                 # no grid yet
+    k = _kps([(5, 5, 0), (14.9, 5, 0), (15.1, 5, 1), (100, 100, 2), (639, 479, 0), (634, 474, 0)])
+    m.grid_build(k, 0.0, 640.0, 0.0, 480.0)
+    off, idx = m.GetFeaturesInArea([10.0, 10.0, -50.0], [5.0, 5.0, 5.0], [6.0, 5.0, 10.0])
+    assert list(off) == [0, 3, 4, 4] and list(idx) == [0, 1, 2, 1]
+    m.grid_build(k[:0], 0.0, 640.0, 0.0, 480.0)                # empty frame
+    off, idx = m.GetFeaturesInArea([10.0], [5.0], 6.0)
+    assert list(off) == [0, 0]
+    bi, bd, sd = m.search_area_best2(np.zeros((1, 32), np.uint8), [10.0], [5.0], 6.0, -1, -1, np.zeros((0, 32), np.uint8))
+    assert (bi[0], bd[0], sd[0]) == (-1, 256, 256)
