@@ -304,14 +304,17 @@ __global__ __launch_bounds__(256) void k_describe(
 #undef D2
                     const uint32_t s4[4] = {e0, e1, o0, o1};
                     uint32_t v4[4];
+                    if (simd_cols == 0) {   // wave-uniform: OpenCV portable C path, (sum + 32768) >> 16 saturated
 #pragma unroll
-                    for (int z = 0; z < 4; z++) {
-                        // OpenCV portable C path: (sum + 32768) >> 16; x86 SSE2 path (columns < simd_cols): the
-                        // same except that an exact .5 tie rounds to even -- branch-free select
-                        uint32_t v = (s4[z] + 32768u) >> 16;
-                        const bool tie_to_even = (x - DESC_R + c + (z & 1) < simd_cols) && ((s4[z] & 0xFFFFu) == 0x8000u) && (v & 1u);
-                        v -= tie_to_even ? 1u : 0u;
-                        v4[z] = min(v, 255u);
+                        for (int z = 0; z < 4; z++) v4[z] = min((s4[z] + 32768u) >> 16, 255u);
+                    } else {                // x86 SSE2 path for columns < simd_cols: an exact .5 tie rounds to even
+#pragma unroll
+                        for (int z = 0; z < 4; z++) {
+                            uint32_t v = (s4[z] + 32768u) >> 16;
+                            const bool tie_to_even = (x - DESC_R + c + (z & 1) < simd_cols) && ((s4[z] & 0xFFFFu) == 0x8000u) && (v & 1u);
+                            v -= tie_to_even ? 1u : 0u;
+                            v4[z] = min(v, 255u);
+                        }
                     }
                     *reinterpret_cast<uint16_t *>(&bl[(2 * q) * DW_BL_STRIDE + c]) = (uint16_t)(v4[0] | (v4[1] << 8));
                     if (2 * q + 1 < DESC_BL)

@@ -83,30 +83,43 @@ __global__ __launch_bounds__(256) void k_resize_linear_4x4(
     const int base = sx[0];
     const int k1 = 8 * (sx[1] - base), k2 = 8 * (sx[2] - base), k3 = 8 * (sx[3] - base);
 
+    // phase 1: issue every load of the 4x4 block (8 row-table words, 24 source dwords) before any use,
+    // so one memory round trip covers the whole block instead of one per row
+    int b0v[4], b1v[4];
+    uint32_t sh8[4][2], wv[4][2][3];
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+        const int y = min(y4 + r, dh - 1);
+        const int sy = tab.yofs[y];
+        const uint32_t bw = *reinterpret_cast<const uint32_t *>(tab.beta + y);
+        b0v[r] = (int)(short)(bw & 0xFFFFu);
+        b1v[r] = (int)(short)(bw >> 16);
+        const int sy0 = min(max(sy, 0), sh - 1), sy1 = min(max(sy + 1, 0), sh - 1);
+#pragma unroll
+        for (int rr = 0; rr < 2; rr++) {
+            const uint8_t *p = S + (long long)(rr ? sy1 : sy0) * sstride + base;
+            sh8[r][rr] = (uint32_t)((uintptr_t)p & 3u);
+            const uint32_t *q = reinterpret_cast<const uint32_t *>(p - sh8[r][rr]);
+            if (CHECK) {
+                wv[r][rr][0] = q[0];
+                wv[r][rr][1] = (reinterpret_cast<const uint8_t *>(q + 2) <= src_end) ? q[1] : 0u;
+                wv[r][rr][2] = (reinterpret_cast<const uint8_t *>(q + 3) <= src_end) ? q[2] : 0u;
+            } else {
+                wv[r][rr][0] = q[0]; wv[r][rr][1] = q[1]; wv[r][rr][2] = q[2];
+            }
+        }
+    }
+    // phase 2: blend
 #pragma unroll
     for (int r = 0; r < 4; r++) {
         const int y = y4 + r;
         if (y >= dh) break;
-        const int sy = tab.yofs[y];
-        const uint32_t bw = *reinterpret_cast<const uint32_t *>(tab.beta + y);
-        const int b0 = (int)(short)(bw & 0xFFFFu), b1 = (int)(short)(bw >> 16);
-        const int sy0 = min(max(sy, 0), sh - 1), sy1 = min(max(sy + 1, 0), sh - 1);
+        const int b0 = b0v[r], b1 = b1v[r];
         int hv[2][4];
 #pragma unroll
         for (int rr = 0; rr < 2; rr++) {
-            const uint8_t *p = S + (long long)(rr ? sy1 : sy0) * sstride + base;
-            const uint32_t sh8 = (uint32_t)((uintptr_t)p & 3u);
-            const uint32_t *q = reinterpret_cast<const uint32_t *>(p - sh8);
-            uint32_t w0, w1, w2;
-            if (CHECK) {
-                w0 = q[0];
-                w1 = (reinterpret_cast<const uint8_t *>(q + 2) <= src_end) ? q[1] : 0u;
-                w2 = (reinterpret_cast<const uint8_t *>(q + 3) <= src_end) ? q[2] : 0u;
-            } else {
-                w0 = q[0]; w1 = q[1]; w2 = q[2];
-            }
-            const uint32_t lo = __builtin_amdgcn_alignbyte(w1, w0, sh8);
-            const uint32_t hi = __builtin_amdgcn_alignbyte(w2, w1, sh8);
+            const uint32_t lo = __builtin_amdgcn_alignbyte(wv[r][rr][1], wv[r][rr][0], sh8[r][rr]);
+            const uint32_t hi = __builtin_amdgcn_alignbyte(wv[r][rr][2], wv[r][rr][1], sh8[r][rr]);
             const unsigned long long w64 = ((unsigned long long)hi << 32) | lo;
             const uint32_t t0 = lo, t1 = (uint32_t)(w64 >> k1), t2 = (uint32_t)(w64 >> k2), t3 = (uint32_t)(w64 >> k3);
             // (S[sx] | S[sx+1] << 16) . (a0 | a1 << 16)
