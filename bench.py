@@ -94,6 +94,7 @@ def main():
     ap.add_argument("--nfeatures", type=int, default=1000)
     ap.add_argument("--batch", type=int, default=64, help="frames per GPU per step")
     ap.add_argument("--subbatches", type=int, default=0, help="0 = library default")
+    ap.add_argument("--no-overlap", action="store_true", help="do not overlap the resize chain with FAST on level 0")
     ap.add_argument("--no-match", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-budget", type=float, default=12.0)
@@ -129,6 +130,8 @@ def main():
     ex = pkg.ORBextractor(NF, 1.2, 8, 20, 7, device=local, max_width=W, max_height=H, max_batch=B)
     if args.subbatches:
         ex.set_subbatches(args.subbatches)
+    if args.no_overlap:
+        ex.set_overlap_pyramid(False)
     cap = ex.cap
     # One flat result buffer per pipeline slot: [B][cap] 28-B keypoints | [B][cap][32] descriptors | [B] counts,
     # so that one gather moves a whole step's results.  Two slots: the gather of step i overlaps step i+1.

@@ -25,6 +25,7 @@ ORBX_OK = 0
 ORBX_E_INVALID, ORBX_E_CAPACITY, ORBX_E_SHAPE, ORBX_E_HIP, ORBX_E_CAND_OVERFLOW, ORBX_E_TREE_OVERFLOW = -1, -2, -3, -4, -5, -6
 ORBX_OPT_BLUR_ROUNDING = 1
 ORBX_OPT_SUBBATCHES = 2
+ORBX_OPT_OVERLAP_PYRAMID = 3
 
 
 class OrbxError(RuntimeError):
@@ -177,6 +178,9 @@ class ORBextractor:
 
     def set_subbatches(self, n):
         _chk(self.L.orbx_set_option(self.h, ORBX_OPT_SUBBATCHES, n))
+
+    def set_overlap_pyramid(self, on):
+        _chk(self.L.orbx_set_option(self.h, ORBX_OPT_OVERLAP_PYRAMID, int(on)))
 
     def set_profiling(self, on):
         _chk(self.L.orbx_set_profiling(self.h, int(on)))

@@ -48,7 +48,7 @@ struct orbx_extractor {
     int blur_mode = 0;
     bool need_clear = true;
     hipStream_t stream = nullptr;
-    hipStream_t aux[ORBX_MAX_SUB - 1] = {}; hipEvent_t ev_fork = nullptr, ev_join[ORBX_MAX_SUB - 1] = {}; int nsub = 1;
+    hipStream_t aux[ORBX_MAX_SUB - 1] = {}; hipEvent_t ev_fork = nullptr, ev_join[ORBX_MAX_SUB - 1] = {}; int nsub = 1; int overlap_pyr = 0;
     // current plan
     int cur_w = 0, cur_h = 0; int last_batch = 0;
     const uint8_t *last_input = nullptr; int last_in_stride = 0; long long last_in_frame = 0;
@@ -281,6 +281,7 @@ extern "C" int orbx_set_option(orbx_extractor *h, int option, int value)
     if (!h) return fail(ORBX_E_INVALID, "NULL handle");
     if (option == ORBX_OPT_BLUR_ROUNDING && (value == 0 || value == 1)) { h->blur_mode = value; h->plan.blur_mode = value; return ORBX_OK; }
     if (option == ORBX_OPT_SUBBATCHES && value >= 1 && value <= ORBX_MAX_SUB) { h->nsub = value; return ORBX_OK; }
+    if (option == ORBX_OPT_OVERLAP_PYRAMID && (value == 0 || value == 1)) { h->overlap_pyr = value; return ORBX_OK; }
     return fail(ORBX_E_INVALID, "unknown option %d=%d", option, value);
 }
 extern "C" int orbx_get_levels(const orbx_extractor *h) { return h ? h->nlevels : 0; }
@@ -405,11 +406,26 @@ static int enqueue(orbx_extractor *h, const uint8_t *d_images, int nframes, int 
         for (int i = 1; i < nsub; i++) HIPCHK(hipStreamWaitEvent(st[i], h->ev_fork, 0));
     }
     if (prof) HIPCHK(hipEventRecord(h->ev[0], s));
-    for (int l = 1; l < h->nlevels; l++)
-        for (int i = 0; i < nsub; i++)
-            orbx_launch_resize(sp[i].lv[l - 1], sp[i].lv[l], h->tabs[l], h->area2[l], f0[i + 1] - f0[i], l == 1 ? src_end : nullptr, st[i]);
-    if (prof) HIPCHK(hipEventRecord(h->ev[1], s));
-    for (int i = 0; i < nsub; i++) orbx_launch_fast(sp[i], sw[i], f0[i + 1] - f0[i], st[i]);
+    // FAST on level 0 needs only the input, so with one sub-batch the resize chain (seven small, latency-bound
+    // launches) runs on a side stream underneath it; the remaining levels' cells wait for the chain.
+    const bool overlap = !prof && nsub == 1 && h->overlap_pyr && h->nlevels > 1 && P.lv[1].cell_begin > 0;
+    if (overlap) {
+        hipStream_t sa = h->aux[ORBX_MAX_SUB - 2];
+        HIPCHK(hipEventRecord(h->ev_fork, s));
+        HIPCHK(hipStreamWaitEvent(sa, h->ev_fork, 0));
+        for (int l = 1; l < h->nlevels; l++)
+            orbx_launch_resize(sp[0].lv[l - 1], sp[0].lv[l], h->tabs[l], h->area2[l], nframes, l == 1 ? src_end : nullptr, sa);
+        HIPCHK(hipEventRecord(h->ev_join[ORBX_MAX_SUB - 2], sa));
+        orbx_launch_fast(sp[0], sw[0], nframes, 0, P.lv[1].cell_begin, s);
+        HIPCHK(hipStreamWaitEvent(s, h->ev_join[ORBX_MAX_SUB - 2], 0));
+        orbx_launch_fast(sp[0], sw[0], nframes, P.lv[1].cell_begin, P.ncells, s);
+    } else {
+        for (int l = 1; l < h->nlevels; l++)
+            for (int i = 0; i < nsub; i++)
+                orbx_launch_resize(sp[i].lv[l - 1], sp[i].lv[l], h->tabs[l], h->area2[l], f0[i + 1] - f0[i], l == 1 ? src_end : nullptr, st[i]);
+        if (prof) HIPCHK(hipEventRecord(h->ev[1], s));
+        for (int i = 0; i < nsub; i++) orbx_launch_fast(sp[i], sw[i], f0[i + 1] - f0[i], 0, P.ncells, st[i]);
+    }
     if (prof) HIPCHK(hipEventRecord(h->ev[2], s));
     for (int i = 0; i < nsub; i++) orbx_launch_octree(sp[i], sw[i], f0[i + 1] - f0[i], h->oct_lds, st[i]);
     if (prof) HIPCHK(hipEventRecord(h->ev[3], s));

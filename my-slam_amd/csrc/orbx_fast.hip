@@ -110,13 +110,13 @@ __device__ __forceinline__ void fast_stage2(const uint8_t *T0, const uint16_t *q
 }
 
 template <int TS, int TH, int ZS>
-__global__ __launch_bounds__(FAST_THREADS) void k_fast_cells(OrbxPlan plan, OrbxWork wk, int l0_aligned)
+__global__ __launch_bounds__(FAST_THREADS) void k_fast_cells(OrbxPlan plan, OrbxWork wk, int l0_aligned, int cell_lo, int cell_hi)
 {
     __shared__ __attribute__((aligned(16))) FastLds<TS, TH, ZS> lds[FAST_THREADS / 64];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int cell = blockIdx.x * (FAST_THREADS / 64) + wave, f = blockIdx.y;
-    if (cell >= plan.ncells) return;
+    const int cell = cell_lo + blockIdx.x * (FAST_THREADS / 64) + wave, f = blockIdx.y;
+    if (cell >= cell_hi) return;
     FastLds<TS, TH, ZS> &S = lds[wave];
 
     int l = 0;
@@ -304,17 +304,18 @@ __global__ __launch_bounds__(FAST_THREADS) void k_fast_cells(OrbxPlan plan, Orbx
     }
 }
 
-void orbx_launch_fast(const OrbxPlan &plan, const OrbxWork &wk, int nframes, hipStream_t s)
+void orbx_launch_fast(const OrbxPlan &plan, const OrbxWork &wk, int nframes, int cell_lo, int cell_hi, hipStream_t s)
 {
-    if (plan.ncells <= 0) return;
+    cell_hi = min(cell_hi, plan.ncells);
+    if (cell_hi <= cell_lo) return;
     int maxcell = 0;
     for (int l = 0; l < plan.nlevels; l++)
         if (plan.lv[l].nCols > 0) maxcell = max(maxcell, max(plan.lv[l].wCell, plan.lv[l].hCell));
     const OrbxLevel &L0 = plan.lv[0];
     const int l0_aligned = (((uintptr_t)L0.base | (uintptr_t)L0.stride | (uintptr_t)L0.frame_stride) & 3) == 0;
-    dim3 grid((plan.ncells + FAST_THREADS / 64 - 1) / (FAST_THREADS / 64), nframes);
+    dim3 grid((cell_hi - cell_lo + FAST_THREADS / 64 - 1) / (FAST_THREADS / 64), nframes);
     if (maxcell <= 38)   // tile <= 44x44, zone <= 38x38; row = 4 pad + 3 + 44 + over-read -> 56 B
-        hipLaunchKernelGGL((k_fast_cells<56, 44, 40>), grid, dim3(FAST_THREADS), 0, s, plan, wk, l0_aligned);
+        hipLaunchKernelGGL((k_fast_cells<56, 44, 40>), grid, dim3(FAST_THREADS), 0, s, plan, wk, l0_aligned, cell_lo, cell_hi);
     else                 // cells of tiny levels: tile <= 66x66, zone <= 60x60
-        hipLaunchKernelGGL((k_fast_cells<80, 66, 64>), grid, dim3(FAST_THREADS), 0, s, plan, wk, l0_aligned);
+        hipLaunchKernelGGL((k_fast_cells<80, 66, 64>), grid, dim3(FAST_THREADS), 0, s, plan, wk, l0_aligned, cell_lo, cell_hi);
 }

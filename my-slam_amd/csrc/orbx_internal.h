@@ -90,7 +90,8 @@ enum { RESIZE_FAST = 0, RESIZE_AREA2 = 1, RESIZE_GENERIC = 2 };
 // src_end != NULL: the source is caller-owned memory; one past its last valid byte (fast path guard)
 void orbx_launch_resize(const OrbxLevel &src, const OrbxLevel &dst, const ResizeTab &tab, int mode,
                         int nframes, const uint8_t *src_end, hipStream_t s);
-void orbx_launch_fast(const OrbxPlan &plan, const OrbxWork &wk, int nframes, hipStream_t s);
+// cells [cell_lo, cell_hi) of the per-frame cell list (level 0 comes first)
+void orbx_launch_fast(const OrbxPlan &plan, const OrbxWork &wk, int nframes, int cell_lo, int cell_hi, hipStream_t s);
 void orbx_launch_octree(const OrbxPlan &plan, const OrbxWork &wk, int nframes, size_t lds_bytes,
                         hipStream_t s);
 void orbx_launch_describe(const OrbxPlan &plan, const OrbxWork &wk, int nframes,
