@@ -119,6 +119,17 @@ int orbx_download_candidates(orbx_extractor *h, int frame, int level, int32_t *x
 int orbx_last_stage_ms(orbx_extractor *h, float ms[4]);
 int orbx_set_profiling(orbx_extractor *h, int enabled);
 
+/*
+ * "next" row N3: Frame::ComputeStereoMatches (src/Frame.cc:466-640) on the GPU.  `left` and
+ * `right` are the two extractor handles of the stereo rig (src/Frame.cc:78-81); the pyramids of their last
+ * orbx_extract call (mvImagePyramid) are read in place.  Inputs are that call's keypoints/descriptors
+ * (host); mb = mbf/fx, mbf as in Frame.  Outputs mvuRight / mvDepth (nl floats, -1 = no match).
+ */
+int orbx_stereo_matches(orbx_extractor *left, orbx_extractor *right,
+                        const orbx_keypoint *kl, const uint8_t *dl, int nl,
+                        const orbx_keypoint *kr, const uint8_t *dr, int nr,
+                        float mb, float mbf, float *u_right, float *depth);
+
 const char *orbx_last_error(void);
 const char *orbx_version(void);
 

@@ -80,6 +80,8 @@ def lib():
     L.orbx_last_error.restype = C.c_char_p
     L.orbx_version.restype = C.c_char_p
     L.orbx_debug_sincos.argtypes = [vp, vp, vp, C.c_int]
+    L.orbx_stereo_matches.argtypes = [vp, vp, vp, vp, C.c_int, vp, vp, C.c_int, C.c_float, C.c_float, vp, vp]
+    L.orbx_stereo_matches.restype = C.c_int
     for name in ("orbx_set_option", "orbx_get_levels", "orbx_get_tables", "orbx_get_features_per_level",
                  "orbx_capacity", "orbx_extract", "orbx_extract_batch", "orbx_extract_batch_device",
                  "orbx_level_size", "orbx_download_level", "orbx_download_candidates", "orbx_last_stage_ms",
@@ -241,6 +243,15 @@ class ORBextractor:
         if n < 0:
             _chk(n)
         return a[:n].copy()
+
+
+def ComputeStereoMatches(left, right, kl, dl, kr, dr, mb, mbf):
+    """Frame::ComputeStereoMatches on the two extractors' last pyramids -> (mvuRight, mvDepth)."""
+    kl = np.ascontiguousarray(kl, KP_DTYPE); kr = np.ascontiguousarray(kr, KP_DTYPE)
+    dl = np.ascontiguousarray(dl, np.uint8); dr = np.ascontiguousarray(dr, np.uint8)
+    u = np.zeros(len(kl), np.float32); d = np.zeros(len(kl), np.float32)
+    _chk(lib().orbx_stereo_matches(left.h, right.h, _p(kl), _p(dl), len(kl), _p(kr), _p(dr), len(kr), mb, mbf, _p(u), _p(d)))
+    return u, d
 
 
 def debug_sincos(theta):

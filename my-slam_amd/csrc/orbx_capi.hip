@@ -579,3 +579,18 @@ extern "C" int orbx_download_candidates(orbx_extractor *h, int frame, int level,
     }
     return (int)n;
 }
+
+// pyramid description of the last call (frame 0) for the stereo matcher (orbx_stereo.hip)
+int orbx_internal_levels(orbx_extractor *h, const uint8_t **base, int *w, int *hh, int *stride, float *scale, float *inv_scale, int *nlevels, int *device)
+{
+    if (!h || h->cur_w == 0 || h->last_batch < 1) return ORBX_E_INVALID;
+    *nlevels = h->nlevels; *device = h->device;
+    for (int l = 0; l < h->nlevels; l++) {
+        const OrbxLevel &L = h->plan.lv[l];
+        base[l] = l == 0 ? h->last_input : L.base;
+        stride[l] = l == 0 ? h->last_in_stride : L.stride;
+        w[l] = L.w; hh[l] = L.h;
+        scale[l] = h->scale[l]; inv_scale[l] = h->inv_scale[l];
+    }
+    return ORBX_OK;
+}

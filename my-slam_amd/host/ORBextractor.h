@@ -89,6 +89,7 @@ public:
         }
         return true;
     }
+    orbx_extractor *handle() { return h_; }   // for orbx_stereo_matches (Frame::ComputeStereoMatches)
     bool Valid() const { return h_ != nullptr; }
     const std::string &LastError() const { return err_; }
 

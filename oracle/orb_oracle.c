@@ -1060,3 +1060,122 @@ void oro_search_area_best2(const oro_grid *g, const oro_keypoint *kps_un, const 
     }
     free(idx);
 }
+
+/* ------------------------------------------------------------------------------------------------
+ * N3: Frame::ComputeStereoMatches (src/Frame.cc:466-640)
+ * ---------------------------------------------------------------------------------------------- */
+static int cmp_pair_ii(const void *a, const void *b)
+{
+    const int *x = (const int *)a, *y = (const int *)b;
+    if (x[0] != y[0]) return x[0] < y[0] ? -1 : 1;
+    return x[1] < y[1] ? -1 : (x[1] > y[1] ? 1 : 0);
+}
+
+void oro_stereo_matches(const oro_extractor *e, const oro_keypoint *kl, const uint8_t *dl, int N,
+                        const oro_keypoint *kr, const uint8_t *dr, int Nr,
+                        uint8_t *const *pyrL, uint8_t *const *pyrR, const int *lw, const int *lh,
+                        float mb, float mbf, float *mvuRight, float *mvDepth)
+{
+    for (int i = 0; i < N; i++) { mvuRight[i] = -1.0f; mvDepth[i] = -1.0f; }
+    const int thOrbDist = (100 + 50) / 2;                       /* (TH_HIGH+TH_LOW)/2 :471 */
+    const int nRows = lh[0];
+    /* :476-494 row table: right keypoint iR is a candidate for every row in [floor(y-r), ceil(y+r)] */
+    int *rcnt = (int *)calloc((size_t)nRows + 1, sizeof(int));
+    for (int iR = 0; iR < Nr; iR++) {
+        const float kpY = kr[iR].y, r = 2.0f * e->scale[kr[iR].octave];
+        const int maxr = (int)ceilf(kpY + r), minr = (int)floorf(kpY - r);
+        for (int yi = minr; yi <= maxr; yi++) if (yi >= 0 && yi < nRows) rcnt[yi]++;
+    }
+    int *rstart = (int *)malloc(sizeof(int) * ((size_t)nRows + 1));
+    rstart[0] = 0;
+    for (int y = 0; y < nRows; y++) rstart[y + 1] = rstart[y] + rcnt[y];
+    int *ritems = (int *)malloc(sizeof(int) * (size_t)(rstart[nRows] ? rstart[nRows] : 1));
+    memset(rcnt, 0, sizeof(int) * (size_t)nRows);
+    for (int iR = 0; iR < Nr; iR++) {
+        const float kpY = kr[iR].y, r = 2.0f * e->scale[kr[iR].octave];
+        const int maxr = (int)ceilf(kpY + r), minr = (int)floorf(kpY - r);
+        for (int yi = minr; yi <= maxr; yi++) if (yi >= 0 && yi < nRows) ritems[rstart[yi] + rcnt[yi]++] = iR;
+    }
+    const float minZ = mb, minD = 0, maxD = mbf / minZ;        /* :497-499 */
+    int *vDistIdx = (int *)malloc(sizeof(int) * 2 * (size_t)(N ? N : 1));
+    int nd = 0;
+    for (int iL = 0; iL < N; iL++) {
+        const oro_keypoint *kpL = &kl[iL];
+        const int levelL = kpL->octave;
+        const float vL = kpL->y, uL = kpL->x;
+        const int row = (int)vL;
+        if (row < 0 || row >= nRows) continue;
+        const int c0 = rstart[row], c1 = rstart[row + 1];
+        if (c0 == c1) continue;
+        const float minU = uL - maxD, maxU = uL - minD;
+        if (maxU < 0) continue;
+        int bestDist = 100;                                     /* TH_HIGH :519 */
+        int bestIdxR = 0;
+        for (int c = c0; c < c1; c++) {
+            const int iR = ritems[c];
+            const oro_keypoint *kpR = &kr[iR];
+            if (kpR->octave < levelL - 1 || kpR->octave > levelL + 1) continue;
+            const float uR = kpR->x;
+            if (uR >= minU && uR <= maxU) {
+                const int dist = oro_descriptor_distance(dl + (size_t)iL * 32, dr + (size_t)iR * 32);
+                if (dist < bestDist) { bestDist = dist; bestIdxR = iR; }
+            }
+        }
+        if (bestDist < thOrbDist) {                             /* :549 subpixel match by correlation */
+            const float uR0 = kr[bestIdxR].x;
+            const float scaleFactor = e->inv_scale[kpL->octave];
+            const float scaleduL = roundf(kpL->x * scaleFactor);
+            const float scaledvL = roundf(kpL->y * scaleFactor);
+            const float scaleduR0 = roundf(uR0 * scaleFactor);
+            const int w = 5, Lw = 5;
+            const int lv = kpL->octave, W = lw[lv], H = lh[lv];
+            const uint8_t *IL = pyrL[lv], *IR = pyrR[lv];
+            const int cvL = (int)scaledvL, cuL = (int)scaleduL, cuR = (int)scaleduR0;
+            int bestD = INT_MAX, bestincR = 0;
+            float vDists[11];
+            const float iniu = scaleduR0 + Lw - w, endu = scaleduR0 + Lw + w + 1;
+            if (iniu < 0 || endu >= W) continue;                /* :575-577 */
+            const int cL = IL[(size_t)cvL * W + cuL];
+            for (int incR = -Lw; incR <= Lw; incR++) {
+                /* the reference reads through its reflect-101 bordered buffer; rows are always inside */
+                const int cR = IR[(size_t)oro_reflect101(cvL, H) * W + oro_reflect101(cuR + incR, W)];
+                int sum = 0;
+                for (int dy = -w; dy <= w; dy++)
+                    for (int dx = -w; dx <= w; dx++) {
+                        const int a = IL[(size_t)oro_reflect101(cvL + dy, H) * W + oro_reflect101(cuL + dx, W)] - cL;
+                        const int b = IR[(size_t)oro_reflect101(cvL + dy, H) * W + oro_reflect101(cuR + incR + dx, W)] - cR;
+                        sum += abs(a - b);
+                    }
+                const float dist = (float)sum;                  /* cv::norm(IL,IR,NORM_L1): exact integers */
+                if (dist < (float)bestD) { bestD = (int)dist; bestincR = incR; }
+                vDists[Lw + incR] = dist;
+            }
+            if (bestincR == -Lw || bestincR == Lw) continue;
+            const float dist1 = vDists[Lw + bestincR - 1], dist2 = vDists[Lw + bestincR], dist3 = vDists[Lw + bestincR + 1];
+            const float deltaR = (dist1 - dist3) / (2.0f * (dist1 + dist3 - 2.0f * dist2));
+            if (deltaR < -1 || deltaR > 1) continue;
+            float bestuR = e->scale[kpL->octave] * ((float)scaleduR0 + (float)bestincR + deltaR);
+            float disparity = (uL - bestuR);
+            if (disparity >= minD && disparity < maxD) {
+                if (disparity <= 0) {
+                    disparity = (float)0.01;
+                    bestuR = (float)((double)uL - 0.01);
+                }
+                mvDepth[iL] = mbf / disparity;
+                mvuRight[iL] = bestuR;
+                vDistIdx[2 * nd] = bestD; vDistIdx[2 * nd + 1] = iL; nd++;
+            }
+        }
+    }
+    if (nd > 0) {                                               /* :627-639 */
+        qsort(vDistIdx, (size_t)nd, 2 * sizeof(int), cmp_pair_ii);
+        const float median = (float)vDistIdx[2 * (nd / 2)];
+        const float thDist = 1.5f * 1.4f * median;
+        for (int i = nd - 1; i >= 0; i--) {
+            if ((float)vDistIdx[2 * i] < thDist) break;
+            mvuRight[vDistIdx[2 * i + 1]] = -1;
+            mvDepth[vDistIdx[2 * i + 1]] = -1;
+        }
+    }
+    free(rcnt); free(rstart); free(ritems); free(vDistIdx);
+}

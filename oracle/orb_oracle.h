@@ -153,6 +153,14 @@ void oro_search_area_best2(const oro_grid *g, const oro_keypoint *kps_un, const 
                            const int32_t *min_level, const int32_t *max_level, int nq,
                            int32_t *best_idx, int32_t *best_d, int32_t *second_d);
 
+/* ---- N3: Frame::ComputeStereoMatches (src/Frame.cc:466-640) ----
+ * pyrL/pyrR: nlevels interior level images (stride = width) of the left/right extractor (mvImagePyramid);
+ * columns left of 0 are read through the reference's 19-px reflect-101 border.  u_right/depth get N floats. */
+void oro_stereo_matches(const oro_extractor *e, const oro_keypoint *kl, const uint8_t *dl, int nl,
+                        const oro_keypoint *kr, const uint8_t *dr, int nr,
+                        uint8_t *const *pyrL, uint8_t *const *pyrR, const int *lw, const int *lh,
+                        float mb, float mbf, float *u_right, float *depth);
+
 #ifdef __cplusplus
 }
 #endif

@@ -84,6 +84,9 @@ def lib(native=False):
     L.oro_features_in_area.restype = C.c_int
     L.oro_search_area_best2.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, C.c_int, vp, vp, vp]
     L.oro_search_area_best2.restype = None
+    L.oro_stereo_matches.argtypes = [C.POINTER(OroExtractor), vp, vp, C.c_int, vp, vp, C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p),
+                                     C.POINTER(C.c_int), C.POINTER(C.c_int), C.c_float, C.c_float, vp, vp]
+    L.oro_stereo_matches.restype = None
     L.oro_match_dense.argtypes = [vp, vp, C.c_int, vp, vp, C.c_int, C.c_int, C.c_float, C.c_int, vp]
     L.oro_match_dense.restype = C.c_int
     if not native:
@@ -226,3 +229,15 @@ class FrameGrid:
         self.L.oro_search_area_best2(C.byref(self.g), _p(self.kps), _p(train_desc), _p(sk) if sk is not None else None,
                                      _p(qdesc), _p(x), _p(y), _p(r), _p(mn), _p(mx), nq, _p(bi), _p(bd), _p(sd))
         return bi, bd, sd
+
+
+def stereo_matches(ex, kl, dl, kr, dr, pyrL, pyrR, mb, mbf):
+    """Frame::ComputeStereoMatches on the oracle; pyrL/pyrR = lists of contiguous level images."""
+    n = len(pyrL)
+    PL = (C.c_void_p * n)(*[a.ctypes.data for a in pyrL]); PR = (C.c_void_p * n)(*[a.ctypes.data for a in pyrR])
+    lw = (C.c_int * n)(*[a.shape[1] for a in pyrL]); lh = (C.c_int * n)(*[a.shape[0] for a in pyrL])
+    kl = np.ascontiguousarray(kl, KP_DTYPE); kr = np.ascontiguousarray(kr, KP_DTYPE)
+    dl = np.ascontiguousarray(dl, np.uint8); dr = np.ascontiguousarray(dr, np.uint8)
+    u = np.zeros(len(kl), np.float32); d = np.zeros(len(kl), np.float32)
+    ex.L.oro_stereo_matches(C.byref(ex.e), _p(kl), _p(dl), len(kl), _p(kr), _p(dr), len(kr), PL, PR, lw, lh, mb, mbf, _p(u), _p(d))
+    return u, d
