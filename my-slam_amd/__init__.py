@@ -88,8 +88,27 @@ def lib():
                  "orbx_set_profiling", "orbx_debug_sincos"):
         getattr(L, name).restype = C.c_int
     _bind_matcher(L)
+    _bind_voc(L)
     _lib = L
     return L
+
+
+def _bind_voc(L):
+    vp = C.c_void_p
+    if not hasattr(L, "orbv_load_text"):
+        return
+    L.orbv_load_text.argtypes = [C.POINTER(vp), C.c_char_p, C.c_int]
+    L.orbv_destroy.argtypes = [vp]
+    L.orbv_destroy.restype = None
+    L.orbv_info.argtypes = [vp] + [C.POINTER(C.c_int)] * 6
+    L.orbv_transform_features.argtypes = [vp, vp, C.c_int, C.c_int, vp, vp, vp]
+    L.orbv_bow_vector.argtypes = [vp, vp, vp, C.c_int, vp, vp, C.c_int]
+    L.orbv_feature_vector.argtypes = [vp, vp, C.c_int, vp, vp, vp, C.c_int]
+    L.orbv_score_l1.argtypes = [vp, vp, C.c_int, vp, vp, C.c_int]
+    L.orbv_score_l1.restype = C.c_double
+    L.orbv_last_error.restype = C.c_char_p
+    for name in ("orbv_load_text", "orbv_info", "orbv_transform_features", "orbv_bow_vector", "orbv_feature_vector"):
+        getattr(L, name).restype = C.c_int
 
 
 def _bind_matcher(L):
@@ -371,3 +390,48 @@ class ORBmatcher:
         _mchk(self.L.orbm_search_area_best2(self.h, _p(qdesc), _p(x), _p(y), _p(r), _p(mn), _p(mx), nq, _p(train_desc), _p(skip),
                                             _p(bi), _p(bd), _p(sd)))
         return bi, bd, sd
+
+
+class ORBVocabulary:
+    """DBoW2 TemplatedVocabulary<FORB> (text format) with the tree descent on the GPU (include/orbv.h)."""
+
+    def __init__(self, path, device=0):
+        self.L = lib()
+        self.h = C.c_void_p()
+        rc = self.L.orbv_load_text(C.byref(self.h), path.encode(), device)
+        if rc != ORBX_OK:
+            raise OrbxError(rc, self.L.orbv_last_error().decode())
+        v = [C.c_int() for _ in range(6)]
+        self.L.orbv_info(self.h, *[C.byref(x) for x in v])
+        self.k, self.depth, self.nnodes, self.nwords, self.scoring, self.weighting = [x.value for x in v]
+
+    def close(self):
+        if getattr(self, "h", None) is not None and self.h:
+            self.L.orbv_destroy(self.h)
+            self.h = None
+
+    __del__ = close
+
+    def transform_features(self, desc, levelsup=4):
+        desc = np.ascontiguousarray(desc, np.uint8).reshape(-1, 32)
+        n = len(desc)
+        w = np.zeros(n, np.int32); nd = np.zeros(n, np.int32); wt = np.zeros(n, np.float64)
+        rc = self.L.orbv_transform_features(self.h, _p(desc), n, levelsup, _p(w), _p(nd), _p(wt))
+        if rc != ORBX_OK:
+            raise OrbxError(rc, self.L.orbv_last_error().decode())
+        return w, nd, wt
+
+    def transform(self, desc, levelsup=4):
+        """transform(features, BowVector, FeatureVector, levelsup) -> ((ids, vals), (node_ids, off, idx))."""
+        w, nd, wt = self.transform_features(desc, levelsup)
+        n = len(w)
+        ids = np.zeros(max(n, 1), np.int32); vals = np.zeros(max(n, 1), np.float64)
+        nb = self.L.orbv_bow_vector(self.h, _p(w), _p(wt), n, _p(ids), _p(vals), len(ids))
+        nids = np.zeros(max(n, 1), np.int32); off = np.zeros(n + 1, np.int32); idx = np.zeros(max(n, 1), np.int32)
+        nn = self.L.orbv_feature_vector(_p(nd), _p(wt), n, _p(nids), _p(off), _p(idx), len(nids))
+        if nb < 0 or nn < 0:
+            raise OrbxError(min(nb, nn), self.L.orbv_last_error().decode())
+        return (ids[:nb].copy(), vals[:nb].copy()), (nids[:nn].copy(), off[:nn + 1].copy(), idx[:off[nn]].copy())
+
+    def score(self, bow1, bow2):
+        return self.L.orbv_score_l1(_p(bow1[0]), _p(bow1[1]), len(bow1[0]), _p(bow2[0]), _p(bow2[1]), len(bow2[0]))

@@ -1179,3 +1179,96 @@ void oro_stereo_matches(const oro_extractor *e, const oro_keypoint *kl, const ui
     }
     free(rcnt); free(rstart); free(ritems); free(vDistIdx);
 }
+
+/* ------------------------------------------------------------------------------------------------
+ * N2: DBoW2 transform (TemplatedVocabulary.h:1127-1259), BowVector.cpp:34-84, FeatureVector.cpp:31-45,
+ * ScoringObject.cpp:23-68
+ * ---------------------------------------------------------------------------------------------- */
+void oro_voc_transform_features(const oro_voc *v, const uint8_t *feat, int n, int levelsup,
+                                int32_t *word_id, int32_t *node_id, double *weight)
+{
+    const int nid_level = v->L - levelsup;
+    for (int i = 0; i < n; i++) {
+        int final_id = 0, current_level = 0, nid = 0;       /* nid_level <= 0 -> root (:1228) */
+        do {
+            ++current_level;
+            const int c0 = v->child_off[final_id], c1 = v->child_off[final_id + 1];
+            final_id = v->child_ids[c0];
+            double best_d = (double)oro_descriptor_distance(feat + (size_t)i * 32, v->desc + (size_t)final_id * 32);
+            for (int c = c0 + 1; c < c1; c++) {
+                const int id = v->child_ids[c];
+                const double d = (double)oro_descriptor_distance(feat + (size_t)i * 32, v->desc + (size_t)id * 32);
+                if (d < best_d) { best_d = d; final_id = id; }
+            }
+            if (current_level == nid_level) nid = final_id;
+        } while (v->child_off[final_id + 1] > v->child_off[final_id]);
+        word_id[i] = v->word_of[final_id];
+        node_id[i] = nid;
+        weight[i] = v->weight[final_id];
+    }
+}
+
+typedef struct { int32_t key; int32_t idx; } key_idx;
+static int cmp_key_idx(const void *a, const void *b)
+{
+    const key_idx *x = (const key_idx *)a, *y = (const key_idx *)b;
+    if (x->key != y->key) return x->key < y->key ? -1 : 1;
+    return x->idx < y->idx ? -1 : (x->idx > y->idx ? 1 : 0);
+}
+
+int oro_voc_bow_vector(const oro_voc *v, const int32_t *word_id, const double *weight, int n, int32_t *ids, double *vals)
+{
+    const int must = v->scoring != 5;          /* DOT_PRODUCT is the only scoring that does not normalise */
+    const int l2 = v->scoring == 1;
+    key_idx *ki = (key_idx *)malloc(sizeof(key_idx) * (size_t)(n ? n : 1));
+    int m = 0;
+    for (int i = 0; i < n; i++) if (weight[i] > 0) { ki[m].key = word_id[i]; ki[m].idx = i; m++; }
+    qsort(ki, (size_t)m, sizeof(key_idx), cmp_key_idx);
+    int o = 0;
+    for (int j = 0; j < m; j++) {
+        const double w = weight[ki[j].idx];
+        if (o > 0 && ids[o - 1] == ki[j].key) {
+            if (v->weighting == 0 || v->weighting == 1) vals[o - 1] += w;   /* addWeight; addIfNotExist keeps the first */
+        } else { ids[o] = ki[j].key; vals[o] = w; o++; }
+    }
+    if ((v->weighting == 0 || v->weighting == 1) && o > 0 && !must) {
+        const double nd = (double)o;
+        for (int j = 0; j < o; j++) vals[j] /= nd;
+    }
+    if (must) {
+        double norm = 0.0;
+        if (!l2) for (int j = 0; j < o; j++) norm += fabs(vals[j]);
+        else { for (int j = 0; j < o; j++) norm += vals[j] * vals[j]; norm = sqrt(norm); }
+        if (norm > 0.0) for (int j = 0; j < o; j++) vals[j] /= norm;
+    }
+    free(ki);
+    return o;
+}
+
+int oro_voc_feature_vector(const int32_t *node_id, const double *weight, int n, int32_t *node_ids, int32_t *off, int32_t *idx)
+{
+    key_idx *ki = (key_idx *)malloc(sizeof(key_idx) * (size_t)(n ? n : 1));
+    int m = 0;
+    for (int i = 0; i < n; i++) if (weight[i] > 0) { ki[m].key = node_id[i]; ki[m].idx = i; m++; }
+    qsort(ki, (size_t)m, sizeof(key_idx), cmp_key_idx);
+    int o = 0;
+    off[0] = 0;
+    for (int j = 0; j < m; j++) {
+        if (o == 0 || node_ids[o - 1] != ki[j].key) { node_ids[o] = ki[j].key; o++; off[o] = off[o - 1]; }
+        idx[off[o]++] = ki[j].idx;
+    }
+    free(ki);
+    return o;
+}
+
+double oro_voc_score_l1(const int32_t *ids1, const double *vals1, int n1, const int32_t *ids2, const double *vals2, int n2)
+{
+    double score = 0;
+    int i = 0, j = 0;
+    while (i < n1 && j < n2) {
+        if (ids1[i] == ids2[j]) { score += fabs(vals1[i] - vals2[j]) - fabs(vals1[i]) - fabs(vals2[j]); i++; j++; }
+        else if (ids1[i] < ids2[j]) i++;
+        else j++;
+    }
+    return -score / 2.0;
+}

@@ -161,6 +161,21 @@ void oro_stereo_matches(const oro_extractor *e, const oro_keypoint *kl, const ui
                         uint8_t *const *pyrL, uint8_t *const *pyrR, const int *lw, const int *lh,
                         float mb, float mbf, float *u_right, float *depth);
 
+/* ---- N2: DBoW2 vocabulary tree (Thirdparty/DBoW2/DBoW2/TemplatedVocabulary.h:1127-1259) ---- */
+typedef struct {
+    int k, L, scoring, weighting, nnodes;
+    const int32_t *child_off;   /* [nnodes+1] */
+    const int32_t *child_ids;   /* children in push_back (file) order */
+    const uint8_t *desc;        /* nnodes x 32 */
+    const int32_t *word_of;     /* leaf -> word id */
+    const double *weight;       /* node weight (idf for leaves) */
+} oro_voc;
+void oro_voc_transform_features(const oro_voc *v, const uint8_t *feat, int n, int levelsup,
+                                int32_t *word_id, int32_t *node_id, double *weight);
+int oro_voc_bow_vector(const oro_voc *v, const int32_t *word_id, const double *weight, int n, int32_t *ids, double *vals);
+int oro_voc_feature_vector(const int32_t *node_id, const double *weight, int n, int32_t *node_ids, int32_t *off, int32_t *idx);
+double oro_voc_score_l1(const int32_t *ids1, const double *vals1, int n1, const int32_t *ids2, const double *vals2, int n2);
+
 #ifdef __cplusplus
 }
 #endif
