@@ -8,10 +8,7 @@
 #define ORBX_MINB 16          // minBorderX/Y = EDGE_THRESHOLD-3, src/ORBextractor.cc:775
 #define ORBX_HALF_PATCH 15    // src/ORBextractor.cc:75
 
-// FAST cell kernel limits (cell zone <= 59x59: wCell = ceil(width/floor(width/30)) < 60)
-#define FAST_TILE_MAX 66
-#define FAST_TILE_STRIDE 68
-#define FAST_ZONE_MAX 60
+// FAST: one wave per cell, 4 waves per workgroup (cell zone <= 59x59: wCell = ceil(width/floor(width/30)) < 60)
 #define FAST_THREADS 256
 
 #define ORBX_CNT_STRIDE 32
@@ -22,12 +19,11 @@
 #endif
 #define OCT_ID_MASK 0x3FFFFFFFu
 
-#define DESC_THREADS 64
 #define DESC_R 18             // rotated rBRIEF sample radius (max |p| = 18.38)
 #define DESC_BL 37            // blurred tile edge  (2*18+1)
 #define DESC_RAW 43           // raw tile edge      (37 + 2*3 for the 7x7 blur)
 
-enum { ERRF_CAND_OVERFLOW = 1, ERRF_TREE_OVERFLOW = 2, ERRF_OUT_OVERFLOW = 4 };
+enum { ERRF_CAND_OVERFLOW = 1, ERRF_TREE_OVERFLOW = 2 };
 
 // One FAST candidate: xy = x | y << 16 (absolute level-interior coordinates), resp = corner score
 struct __attribute__((aligned(8))) OrbxCand { uint32_t xy; uint32_t resp; };
@@ -62,7 +58,6 @@ struct OrbxPlan {
     int ncells;                   // cells per frame over all levels
     int blur_mode;
     int out_cap;                  // per-frame output capacity
-    int dbg;                      // ORBX_DBG_STAGE ablation switch (0 = normal), timing experiments only
     long long cand_frame;         // candidates per frame (elements)
     long long list_frame;         // sel entries per frame
     long long arena_frame;        // arena nodes per frame
@@ -85,7 +80,7 @@ struct ResizeTab {                // per destination level
     const int *xofs; const short2 *alpha; const int *yofs; const short2 *beta;
 };
 
-// ---- launchers (orbx_kernels.hip) ----
+// ---- launchers (orbx_pyramid.hip, orbx_fast.hip, orbx_octree.hip, orbx_describe.hip) ----
 enum { RESIZE_FAST = 0, RESIZE_AREA2 = 1, RESIZE_GENERIC = 2 };
 // src_end != NULL: the source is caller-owned memory; one past its last valid byte (fast path guard)
 void orbx_launch_resize(const OrbxLevel &src, const OrbxLevel &dst, const ResizeTab &tab, int mode,

@@ -140,8 +140,9 @@ __global__ __launch_bounds__(256) void k_stereo(StereoLevels lv, const orbx_keyp
     if (lane == 0) { uRight[iL] = outU; depth[iL] = outD; sad[iL] = outS; }
 }
 
-struct StereoScratch { void *p = nullptr; size_t bytes = 0; };
-static StereoScratch g_scr[16];   // per device
+#include <mutex>
+struct StereoScratch { void *p = nullptr; size_t bytes = 0; std::mutex mu; };
+static StereoScratch g_scr[16];   // per device; a call holds the device's scratch lock (stereo pairs are matched one at a time per device)
 
 // host-side description of a handle's pyramid (orbx_capi.hip)
 int orbx_internal_levels(orbx_extractor *h, const uint8_t **base, int *w, int *hh, int *stride, float *scale, float *inv_scale, int *nlevels, int *device);
@@ -170,6 +171,7 @@ extern "C" int orbx_stereo_matches(orbx_extractor *left, orbx_extractor *right,
     auto al = [](size_t v) { return (v + 255) / 256 * 256; };
     const size_t need = al(bk) + al(bd) + al(brk) + al(brd) + 3 * al(bo) + 256;
     StereoScratch &sc = g_scr[devL & 15];
+    std::lock_guard<std::mutex> lock(sc.mu);
     if (need > sc.bytes) {
         (void)hipFree(sc.p); sc.p = nullptr; sc.bytes = 0;
         if (hipMalloc(&sc.p, need) != hipSuccess) return ORBX_E_HIP;
