@@ -23,6 +23,9 @@
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); \
     } while (0)
 
+#ifndef FAST_REJECT_POINTS
+#define FAST_REJECT_POINTS 4   // stage-1 reject on 4 or 8 circle points (both necessary conditions; results identical)
+#endif
 #define FAST_PADL 4      // left pad (bytes) of every tile row so that dword g-1 exists for every group
 #define FAST_CLIST 256   // corners listed per cell before NMS falls back to scanning the whole score map
 
@@ -57,6 +60,17 @@ __device__ __forceinline__ uint32_t reject8(us2 c, us2 t, us2 a0, us2 a8, us2 a4
 
 typedef short ss2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ ss2 pk(int lo, int hi) { return __builtin_bit_cast(ss2, (uint32_t)(lo & 0xFFFF) | ((uint32_t)hi << 16)); }
+
+// 4-point variant: pairs (0,8) and (4,12) only.  Passes ~20 % more pixels to stage 2 than the 8-point test but
+// costs half of it; measured faster overall on MI355X (the kernel is VALU-bound).
+__device__ __forceinline__ uint32_t reject4(us2 c, us2 t, us2 a0, us2 a8, us2 a4, us2 a12)
+{
+    const us2 mlo = __builtin_elementwise_max(__builtin_elementwise_min(a0, a8), __builtin_elementwise_min(a4, a12));
+    const us2 mhi = __builtin_elementwise_min(__builtin_elementwise_max(a0, a8), __builtin_elementwise_max(a4, a12));
+    const us2 dark = __builtin_elementwise_sub_sat(__builtin_elementwise_sub_sat(c, t), mlo);
+    const us2 bright = __builtin_elementwise_sub_sat(mhi, c + t);
+    return as_u32(dark) | as_u32(bright);
+}
 
 // stage 2 for up to 128 queued survivors, TWO pixels per lane in the two i16 halves of every register:
 // corner score = max over the 16 nine-arcs of min(d) / min(-d), minus 1 (d = centre - circle pixel).
@@ -198,21 +212,26 @@ __global__ __launch_bounds__(FAST_THREADS) void k_fast_cells(OrbxPlan plan, Orbx
             uint32_t f01, f23;
             {
                 const uint32_t *r0 = reinterpret_cast<const uint32_t *>(&S.tile[(zy + 3) * TS]) + g;
-                const uint32_t *rp = reinterpret_cast<const uint32_t *>(&S.tile[(zy + 5) * TS]) + g;
-                const uint32_t *rm = reinterpret_cast<const uint32_t *>(&S.tile[(zy + 1) * TS]) + g;
                 const uint32_t dD = *(reinterpret_cast<const uint32_t *>(&S.tile[(zy + 6) * TS]) + g);   // pixel 0  (0,+3)
                 const uint32_t dU = *(reinterpret_cast<const uint32_t *>(&S.tile[(zy + 0) * TS]) + g);   // pixel 8  (0,-3)
                 const uint32_t cL = r0[-1], cC = r0[0], cR = r0[1];
-                const uint32_t pL = rp[-1], pC = rp[0], pR = rp[1];
-                const uint32_t mL = rm[-1], mC = rm[0], mR = rm[1];
                 const uint32_t d4 = __builtin_amdgcn_alignbyte(cR, cC, 3);    // pixel 4  (+3, 0)
                 const uint32_t d12 = __builtin_amdgcn_alignbyte(cC, cL, 1);   // pixel 12 (-3, 0)
+#if FAST_REJECT_POINTS == 8
+                const uint32_t *rp = reinterpret_cast<const uint32_t *>(&S.tile[(zy + 5) * TS]) + g;
+                const uint32_t *rm = reinterpret_cast<const uint32_t *>(&S.tile[(zy + 1) * TS]) + g;
+                const uint32_t pL = rp[-1], pC = rp[0], pR = rp[1];
+                const uint32_t mL = rm[-1], mC = rm[0], mR = rm[1];
                 const uint32_t d2 = __builtin_amdgcn_alignbyte(pR, pC, 2);    // pixel 2  (+2,+2)
                 const uint32_t d14 = __builtin_amdgcn_alignbyte(pC, pL, 2);   // pixel 14 (-2,+2)
                 const uint32_t d6 = __builtin_amdgcn_alignbyte(mR, mC, 2);    // pixel 6  (+2,-2)
                 const uint32_t d10 = __builtin_amdgcn_alignbyte(mC, mL, 2);   // pixel 10 (-2,-2)
                 f01 = reject8(lo2(cC), tt, lo2(dD), lo2(dU), lo2(d4), lo2(d12), lo2(d2), lo2(d10), lo2(d6), lo2(d14));
                 f23 = reject8(hi2(cC), tt, hi2(dD), hi2(dU), hi2(d4), hi2(d12), hi2(d2), hi2(d10), hi2(d6), hi2(d14));
+#else
+                f01 = reject4(lo2(cC), tt, lo2(dD), lo2(dU), lo2(d4), lo2(d12));
+                f23 = reject4(hi2(cC), tt, hi2(dD), hi2(dU), hi2(d4), hi2(d12));
+#endif
             }
             // append the survivors of the 4 pixels: four ballots, one queue update (entry order is free)
             const bool k0 = (f01 & 0x0000FFFFu) != 0 && zx0 >= 0 && zx0 < zw;
