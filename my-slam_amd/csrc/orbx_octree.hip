@@ -62,42 +62,190 @@ __device__ __forceinline__ void oct_child_box(const OrbxNode &p, int q, OrbxNode
 }
 
 // Only the nodes created by the previous pass can still be split (every older list node holds one
-// key), so the node records live in an LDS window [lastBase, lastBase + lastC): the two key loops
-// of a pass read owner[] and the candidate coordinates with coalesced global loads and look the
-// node up in LDS -- no dependent global gather.  Global memory keeps only owner[] and, at the end,
-// the node-id -> list-position map (the arena buffer reused as int32).
-// The whole distribution of one (frame, level).  LDSKEYS: the keys' coordinates and owners live in LDS
-// (levels with up to OCT_KEYCAP candidates), so the key loops never wait on global memory.
-#define OCT_KEYCAP 6144
-template <int T, bool LDSKEYS>
+// key), so the node records live in an LDS window [lastBase, lastBase + lastC) and the key loop looks
+// them up there -- no dependent global gather.  One key loop per pass: moving a key to its child and
+// counting its quadrant inside that child (the next pass's DivideNode) happen together, with the
+// quadrant counters double-buffered.  The keys themselves (x | y << 16 and the owning node id) live in
+// REGISTERS for the whole kernel: thread t owns candidates t, t + T, t + 2T, ... (KR of them; 8 or 32 per
+// thread, picked by the level's candidate count), so a pass touches no memory but the LDS node window.
+// Levels with more than 32 T candidates fall back to owner[] in global memory, read in batches of 8.
+// Global memory keeps the candidates and, at the end, the node-id -> list-position map (the arena
+// buffer reused as int32).
+
+// -DOCT_TRACE: workgroup (0,0) stamps wall_clock64() (100 MHz) at the section boundaries (tools/dbg/oct_trace.py).
+#ifdef OCT_TRACE
+__device__ unsigned long long g_oct_trace[256];
+#define OCT_T(tag)                                                                              \
+    do {                                                                                        \
+        __syncthreads();                                                                        \
+        if (threadIdx.x == 0 && blockIdx.x == 0 && blockIdx.y == 0 && tp < 255)                 \
+            g_oct_trace[++tp] = ((unsigned long long)(tag) << 56) | (wall_clock64() & 0xFFFFFFFFFFFFFFull); \
+    } while (0)
+#else
+#define OCT_T(tag) do { } while (0)
+#endif
+
+// ++ctr[idx] for every lane with idx >= 0, called by whole waves.  Candidates are stored cell by cell, so neighbouring
+// keys mostly fall into the same node and quadrant: one LDS atomic per lane would serialise (same address); instead each
+// run of equal idx inside the wave adds its length once.
+__device__ __forceinline__ void wave_count(uint32_t *ctr, int idx)
+{
+    const int lane = (int)__lane_id();
+    const int prev = __shfl_up(idx, 1);
+    const bool head = lane == 0 || prev != idx;
+    const unsigned long long hm = __ballot(head);
+    if (head && idx >= 0) {
+        const unsigned long long rest = (hm >> lane) >> 1;
+        const int len = rest ? __ffsll((long long)rest) : 64 - lane;
+        atomicAdd(&ctr[idx], (uint32_t)len);
+    }
+}
+
+// slots for the splittable nodes of a window: phase A = list order (:602-667; the previous pass pushed its
+// children to the front in reverse creation order, the roots are in creation order), phase B = by (size,
+// creation) descending (:686-687).  All phase-B keys are distinct, so a node's slot is the number of larger
+// keys: counted directly (every thread streams the same LDS words: broadcasts) instead of a bitonic sort.
+template <int T>
+__device__ __forceinline__ int oct_assign_slots(OrbxNode *ln, int cntN, bool forward, bool phaseB, uint32_t *slotNode,
+                                                unsigned long long *scratch, OctShared<T> &sh)
+{
+    const int tid = threadIdx.x;
+    if (!phaseB) {
+        int carry = 0;
+        for (int base = 0; base < cntN; base += T) {
+            const int j = base + tid;
+            int cidx = 0, alive = 0;
+            if (j < cntN) {
+                cidx = forward ? j : cntN - 1 - j;
+                alive = ln[cidx].count > 1;
+            }
+            int tot;
+            const int ex = block_excl_scan<T>(alive, &tot, sh.wsum);
+            if (alive) {
+                slotNode[carry + ex] = (uint32_t)cidx;
+                ln[cidx].slot = carry + ex;
+            }
+            carry += tot;
+        }
+        return carry;
+    }
+    // key = count << 12 | index (count < 2^20: cand_cap; index < 4096: list_cap, checked at create time); the splittable
+    // nodes' keys are packed into scratch[] in any order, then ranked
+    uint32_t *keys = reinterpret_cast<uint32_t *>(scratch);
+    if (tid == 0) sh.nAlive = 0;
+    __syncthreads();
+    for (int base = 0; base < cntN; base += T) {
+        const int j = base + tid;
+        const int c = j < cntN ? ln[j].count : 0;
+        const unsigned long long am = __ballot(c > 1);
+        int wbase = 0;
+        if (__lane_id() == 0 && am) wbase = atomicAdd(&sh.nAlive, __popcll(am));
+        wbase = __shfl(wbase, 0);
+        if (c > 1) keys[wbase + __popcll(am & ((1ull << __lane_id()) - 1ull))] = ((uint32_t)c << 12) | (uint32_t)j;
+    }
+    __syncthreads();
+    const int nA = sh.nAlive;
+    for (int i = nA + tid; i < ((nA + 3) & ~3); i += T) keys[i] = 0;   // pad to whole uint4 reads
+    __syncthreads();
+    const uint4 *k4 = reinterpret_cast<const uint4 *>(keys);
+    for (int a = tid; a < nA; a += T) {
+        const uint32_t key = keys[a];
+        int r = 0;
+        for (int i = 0; i < (nA + 3) >> 2; i++) {
+            const uint4 v = k4[i];
+            r += (v.x > key) + (v.y > key) + (v.z > key) + (v.w > key);
+        }
+        const int j = (int)(key & 0xFFFu);
+        slotNode[r] = (uint32_t)j;
+        ln[j].slot = r;
+    }
+    __syncthreads();
+    return nA;
+}
+
+__device__ __forceinline__ uint32_t oct_quadrant(const OrbxNode &nd, uint32_t xy)
+{
+    asm volatile("" : "+v"(xy));   // unpack here, every time: hoisting x and y out of the pass loop costs 2 more registers per key
+    const int xr = (int)(xy & 0xFFFFu) - ORBX_MINB, yr = (int)(xy >> 16) - ORBX_MINB;
+    const int midx = nd.x0 + ((nd.x1 - nd.x0 + 1) >> 1), midy = nd.y0 + ((nd.y1 - nd.y0 + 1) >> 1);
+    return (xr < midx ? 0u : 1u) | (yr < midy ? 0u : 2u);      // :517-527
+}
+
+template <int T, int KR>
 __device__ __forceinline__ void oct_body(const OrbxPlan &plan, const OrbxWork &wk, OctShared<T> &sh, const OrbxLevel &L,
                                          const int f, const int l, const int n, const int cap, const int N,
-                                         uint32_t *cnt, uint32_t *listA, uint32_t *listB, uint32_t *slotNode, int *childBase,
-                                         OrbxNode *lnA, OrbxNode *lnB, uint32_t *kxy, uint32_t *kown,
+                                         uint32_t *cnt0, uint32_t *cnt1, uint32_t *listA, uint32_t *listB, uint32_t *slotNode,
+                                         int *childBase, OrbxNode *lnA, OrbxNode *lnB,
                                          const OrbxCand *__restrict__ cand, uint32_t *__restrict__ owner,
                                          int32_t *__restrict__ posOf, OrbxCand *__restrict__ sel)
 {
-#define KXY(k) (LDSKEYS ? kxy[(k)] : cand[(k)].xy)
-#define OWN(k) (*(LDSKEYS ? &kown[(k)] : &owner[(k)]))
+    // Key loops.  REG: every key is in wv[]/xyv[] already.  Otherwise each thread first issues the loads of 8 keys
+    // (the loop is latency-bound), then processes them.  The trip counts are wave-uniform: wave_count() is wave-wide.
+    constexpr bool REG = KR > 0;
+    constexpr int KU = REG ? KR : 8;
+    uint32_t wv[KU], xyv[KU];
+#define KEYLOOP_BEGIN(LD_OWN, LD_XY)                                    \
+    for (int kb = 0; kb < n; kb += T * KU) {                            \
+        int tidv = tid;                                                 \
+        asm volatile("" : "+v"(tidv));   /* recompute k-derived values per loop instead of keeping them live */ \
+        if (!REG) {                                                     \
+            _Pragma("unroll") for (int u = 0; u < KU; u++) {            \
+                const int k = kb + u * T + tidv;                        \
+                if (k < n) {                                            \
+                    if (LD_OWN) wv[u] = owner[k];                       \
+                    if (LD_XY) xyv[u] = cand[k].xy;                     \
+                }                                                       \
+            }                                                           \
+        }                                                               \
+        _Pragma("unroll") for (int u = 0; u < KU; u++) {                \
+            if (kb + u * T >= n) break;                                 \
+            const int k = kb + u * T + tidv;                            \
+            int ai = -1;      /* counter this key increments, if any */ \
+            if (k < n) {
+#define SETOWN(v)                                                       \
+    do {                                                                \
+        wv[u] = (v);                                                    \
+        if (!REG) owner[k] = wv[u];                                     \
+    } while (0)
+#define KEYLOOP_END_COUNT(ctr)                                          \
+            }                                                           \
+            wave_count(ctr, ai);                                        \
+            if ((u & 3) == 3) __builtin_amdgcn_sched_barrier(0);   /* keep the live ranges of 4 keys, not of all KU */ \
+        }                                                               \
+    }
+#define KEYLOOP_END                                                     \
+            }                                                           \
+            (void)ai;                                                   \
+            if ((u & 3) == 3) __builtin_amdgcn_sched_barrier(0);        \
+        }                                                               \
+    }
     const int tid = threadIdx.x;
-    unsigned long long *sortbuf = reinterpret_cast<unsigned long long *>(cnt);   // alias, phase B
-    unsigned long long *best = reinterpret_cast<unsigned long long *>(cnt);      // alias, final
-    if (LDSKEYS)
-        for (int k = tid; k < n; k += T) kxy[k] = cand[k].xy;
+#ifdef OCT_TRACE
+    int tp = 0;
+#endif
+    OCT_T(0);
+    uint32_t *cc = cnt0, *cn = cnt1;          // quadrant counters of this pass (later: child ids) / of the next pass
+    if (REG) {
+#pragma unroll
+        for (int u = 0; u < KU; u++) {
+            const int k = u * T + tid;
+            xyv[u] = k < n ? cand[k].xy : 0u;
+            wv[u] = 0;
+        }
+    }
     const int nIni = L.nIni;
     const int boxH = L.maxBY - ORBX_MINB;
 
-    // ---- roots (:554-572) ----
-    for (int i = tid; i < nIni; i += T) cnt[i] = 0;
-    if (tid == 0) { sh.err = 0; sh.phaseB = 0; sh.done = 0; sh.firstPass = 1; sh.nToExpand = 0; }
+    // ---- roots (:554-587) ----
+    for (int i = tid; i < nIni; i += T) cc[i] = 0;
     __syncthreads();
-    for (int k = tid; k < n; k += T) {
-        const int xr = (int)(KXY(k) & 0xFFFFu) - ORBX_MINB;
+    KEYLOOP_BEGIN(false, true)
+        const int xr = (int)(xyv[u] & 0xFFFFu) - ORBX_MINB;
         int b = (int)__fdiv_rn((float)xr, L.hX);
         b = min(max(b, 0), nIni - 1);
-        OWN(k) = (uint32_t)b;
-        atomicAdd(&cnt[b], 1u);
-    }
+        SETOWN((uint32_t)b);
+        ai = b;
+    KEYLOOP_END_COUNT(cc)
     __syncthreads();
     for (int i = tid; i < nIni; i += T) {
         OrbxNode nd;
@@ -105,98 +253,49 @@ __device__ __forceinline__ void oct_body(const OrbxPlan &plan, const OrbxWork &w
         nd.x1 = (int16_t)(int)__fmul_rn(L.hX, (float)(i + 1));
         nd.y0 = 0;
         nd.y1 = (int16_t)boxH;
-        nd.count = (int)cnt[i];
+        nd.count = (int)cc[i];
         nd.slot = i;
         lnA[i] = nd;
     }
     __syncthreads();
-    if (tid == 0) {   // initial list: non-empty roots in order (:574-587); nIni is small
+    if (tid == 0) {   // initial list: non-empty roots in order; nIni is small
         int m = 0;
         for (int i = 0; i < nIni; i++)
-            if (cnt[i] > 0) listA[m++] = (uint32_t)i;
-        sh.m = m; sh.arenaN = nIni; sh.lastBase = 0; sh.lastC = nIni;
+            if (cc[i] > 0) listA[m++] = (uint32_t)i;
+        sh.m = m; sh.done = 0; sh.phaseB = 0;
     }
     __syncthreads();
+    OCT_T(1);
     uint32_t *cur = listA, *nxt = listB;
-
-    // ---- expansion passes ----
-    while (true) {
-        const int m = sh.m, lastBase = sh.lastBase, lastC = sh.lastC, arenaN = sh.arenaN;
-        const int phaseB = sh.phaseB, firstPass = sh.firstPass;
-        __syncthreads();
-        // S1: slots for the alive nodes (all of them were created by the previous pass)
-        int nAlive;
-        if (!phaseB) {
-            int carry = 0;
-            for (int base = 0; base < lastC; base += T) {
-                const int j = base + tid;
-                int cidx = 0, alive = 0;
-                if (j < lastC) {
-                    cidx = firstPass ? j : lastC - 1 - j;   // list order of the last children
-                    alive = lnA[cidx].count > 1;
-                }
-                int tot;
-                const int ex = block_excl_scan<T>(alive, &tot, sh.wsum);
-                if (alive) {
-                    slotNode[carry + ex] = (uint32_t)cidx;
-                    lnA[cidx].slot = carry + ex;
-                }
-                carry += tot;
-            }
-            nAlive = carry;
-        } else {
-            // order by (size, creation) descending (:686-687).  All keys are distinct, so a node's slot is the
-            // number of larger keys: counted directly (every thread streams the same LDS words: broadcasts)
-            // instead of log^2 barrier-separated bitonic stages.
-            if (tid == 0) sh.nAlive = 0;
-            for (int j = tid; j < lastC; j += T) {
-                const int c = lnA[j].count;
-                sortbuf[j] = c > 1 ? (((unsigned long long)(uint32_t)c << 32) | (uint32_t)j) : 0ull;
-            }
-            __syncthreads();
-            int mine = 0;
-            for (int j = tid; j < lastC; j += T) {
-                const unsigned long long key = sortbuf[j];
-                if (key != 0) {
-                    int r = 0;
-                    for (int i = 0; i < lastC; i++) r += sortbuf[i] > key;
-                    slotNode[r] = (uint32_t)j;
-                    lnA[j].slot = r;
-                    mine++;
-                }
-            }
-            if (mine) atomicAdd(&sh.nAlive, mine);
-            __syncthreads();
-            nAlive = sh.nAlive;
+    int m = sh.m, arenaN = nIni, lastBase = 0, lastC = nIni, phaseB = 0;
+    // first DivideNode of every splittable root: slots, then one key loop that counts quadrants
+    int nAlive = oct_assign_slots<T>(lnA, lastC, true, false, slotNode, reinterpret_cast<unsigned long long *>(cn), sh);
+    __syncthreads();
+    for (int i = tid; i < 4 * nAlive; i += T) cc[i] = 0;
+    __syncthreads();
+    KEYLOOP_BEGIN(true, true)
+        const uint32_t id = wv[u];
+        const OrbxNode nd = lnA[id];
+        if (nd.count > 1) {
+            const uint32_t q = oct_quadrant(nd, xyv[u]);
+            ai = 4 * nd.slot + (int)q;
+            SETOWN(id | (q << 30));
         }
-        __syncthreads();
-        // S2: zero the quadrant counters
-        for (int i = tid; i < 4 * nAlive; i += T) cnt[i] = 0;
+    KEYLOOP_END_COUNT(cc)
+    __syncthreads();
+
+    OCT_T(2);
+    // ---- expansion passes.  Invariant at the top: lnA = node window [lastBase, lastBase+lastC) with slots
+    // assigned to its nAlive splittable nodes, cc = their quadrant counts, OWN = node id | quadrant << 30 ----
+    while (true) {
         if (tid == 0) { sh.cutoff = 0x7FFFFFFF; sh.nToExpand = 0; }
         __syncthreads();
-        // S3: quadrant of every key held by an alive node (:513-528)
-#pragma unroll 2
-        for (int k = tid; k < n; k += T) {
-            const uint32_t id = OWN(k);
-            if ((int)id >= lastBase) {
-                const OrbxNode nd = lnA[id - lastBase];
-                if (nd.count > 1) {
-                    const uint32_t xy = KXY(k);
-                    const int xr = (int)(xy & 0xFFFFu) - ORBX_MINB, yr = (int)(xy >> 16) - ORBX_MINB;
-                    const int midx = nd.x0 + ((nd.x1 - nd.x0 + 1) >> 1), midy = nd.y0 + ((nd.y1 - nd.y0 + 1) >> 1);
-                    const uint32_t q = (xr < midx ? 0u : 1u) | (yr < midy ? 0u : 2u);
-                    atomicAdd(&cnt[4 * nd.slot + q], 1u);
-                    OWN(k) = id | (q << 30);
-                }
-            }
-        }
-        __syncthreads();
-        // S4: children per slot, prefix sums, phase-B cut-off
+        // children per slot, prefix sums, phase-B cut-off (:732)
         int carry = 0;
         for (int base = 0; base < nAlive; base += T) {
             const int s = base + tid;
             int ne = 0;
-            if (s < nAlive) ne = (cnt[4 * s] > 0) + (cnt[4 * s + 1] > 0) + (cnt[4 * s + 2] > 0) + (cnt[4 * s + 3] > 0);
+            if (s < nAlive) ne = (cc[4 * s] > 0) + (cc[4 * s + 1] > 0) + (cc[4 * s + 2] > 0) + (cc[4 * s + 3] > 0);
             int tot;
             const int ex = block_excl_scan<T>(ne, &tot, sh.wsum);
             if (s < nAlive) {
@@ -210,21 +309,21 @@ __device__ __forceinline__ void oct_body(const OrbxPlan &plan, const OrbxWork &w
         if (phaseB && sh.cutoff != 0x7FFFFFFF) {
             nE = sh.cutoff + 1;
             const int s = nE - 1;
-            C = childBase[s] + (cnt[4 * s] > 0) + (cnt[4 * s + 1] > 0) + (cnt[4 * s + 2] > 0) + (cnt[4 * s + 3] > 0);
+            C = childBase[s] + (cc[4 * s] > 0) + (cc[4 * s + 1] > 0) + (cc[4 * s + 2] > 0) + (cc[4 * s + 3] > 0);
         }
+        OCT_T(3);
         const int survivors = m - nE;
         if (arenaN + C > L.arena_cap || C + survivors > cap) {
             if (tid == 0) { atomicOr(&wk.errflags[f], (uint32_t)ERRF_TREE_OVERFLOW); wk.nk[f * plan.nlevels + l] = 0; }
             return;
         }
-        __syncthreads();
-        // S5: create the children (:489-537) in creation order; cnt becomes the child-id table
+        // create the children (:489-537) in creation order; cc becomes the child-id table
         int myExp = 0;
         for (int s = tid; s < nE; s += T) {
             const OrbxNode p = lnA[slotNode[s]];
             int r = 0;
             for (int q = 0; q < 4; q++) {
-                const int c = (int)cnt[4 * s + q];
+                const int c = (int)cc[4 * s + q];
                 if (c > 0) {
                     const int cidx = childBase[s] + r;
                     OrbxNode ch;
@@ -232,28 +331,17 @@ __device__ __forceinline__ void oct_body(const OrbxPlan &plan, const OrbxWork &w
                     ch.count = c;
                     ch.slot = cidx;
                     lnB[cidx] = ch;
-                    cnt[4 * s + q] = (uint32_t)(arenaN + cidx);
+                    cc[4 * s + q] = (uint32_t)(arenaN + cidx);
                     nxt[C - 1 - cidx] = (uint32_t)(arenaN + cidx);   // push_front => reversed
                     myExp += c > 1;
                     r++;
                 } else {
-                    cnt[4 * s + q] = 0xFFFFFFFFu;
+                    cc[4 * s + q] = 0xFFFFFFFFu;
                 }
             }
         }
         if (myExp) atomicAdd(&sh.nToExpand, myExp);
-        __syncthreads();
-        // S6: move the keys of expanded nodes to their children
-#pragma unroll 2
-        for (int k = tid; k < n; k += T) {
-            const uint32_t w = OWN(k);
-            const uint32_t id = w & OCT_ID_MASK;
-            if ((int)id >= lastBase) {
-                const OrbxNode nd = lnA[id - lastBase];
-                if (nd.count > 1) OWN(k) = nd.slot < nE ? cnt[4 * nd.slot + (w >> 30)] : id;
-            }
-        }
-        // S7: survivors keep their relative order behind the new children
+        // survivors keep their relative order behind the new children
         int scarry = 0;
         for (int base = 0; base < m; base += T) {
             const int i = base + tid;
@@ -273,53 +361,113 @@ __device__ __forceinline__ void oct_body(const OrbxPlan &plan, const OrbxWork &w
             scarry += tot;
         }
         __syncthreads();
-        // S8: bookkeeping + termination (:671-675, :736)
-        if (tid == 0) {
-            const int newM = C + scarry;
-            sh.prevM = m;
-            sh.m = newM;
-            sh.lastBase = arenaN;
-            sh.lastC = C;
-            sh.arenaN = arenaN + C;
-            sh.firstPass = 0;
-            if (newM >= N || newM == m) sh.done = 1;
-            else if (!phaseB && newM + 3 * sh.nToExpand > N) sh.phaseB = 1;
-        }
+        OCT_T(4);
+        // termination and phase switch (:671-675, :736)
+        const int newM = C + scarry;
+        const bool done = newM >= N || newM == m;
+        const int phaseBnext = phaseB || (!done && newM + 3 * sh.nToExpand > N);
         __syncthreads();
+        if (done) {
+            // move the keys of expanded nodes to their children; the rest keep their node
+            KEYLOOP_BEGIN(true, false)
+                const uint32_t w = wv[u];
+                const uint32_t id = w & OCT_ID_MASK;
+                if ((int)id >= lastBase) {
+                    const OrbxNode nd = lnA[id - lastBase];
+                    if (nd.count > 1) SETOWN(nd.slot < nE ? cc[4 * nd.slot + (w >> 30)] : id);
+                }
+            KEYLOOP_END
+            m = newM;
+            { uint32_t *t2 = cur; cur = nxt; nxt = t2; }
+            break;
+        }
+        // not finished: every splittable node was expanded (a phase-B cut-off always finishes), so all live keys move.
+        // Slots for the children, then ONE key loop: key -> child, and its quadrant inside that child.
+        const int nAliveNext = oct_assign_slots<T>(lnB, C, false, phaseBnext != 0, slotNode, reinterpret_cast<unsigned long long *>(cn), sh);
+        OCT_T(phaseBnext ? 6 : 5);
+        for (int i = tid; i < 4 * nAliveNext; i += T) cn[i] = 0;
+        __syncthreads();
+        KEYLOOP_BEGIN(true, true)
+            const uint32_t w = wv[u];
+            const uint32_t id = w & OCT_ID_MASK;
+            if ((int)id >= lastBase) {
+                const OrbxNode nd = lnA[id - lastBase];
+                if (nd.count > 1) {
+                    const uint32_t child = cc[4 * nd.slot + (w >> 30)];
+                    const OrbxNode ch = lnB[child - arenaN];
+                    if (ch.count > 1) {
+                        const uint32_t q = oct_quadrant(ch, xyv[u]);
+                        ai = 4 * ch.slot + (int)q;
+                        SETOWN(child | (q << 30));
+                    } else {
+                        SETOWN(child);
+                    }
+                }
+            }
+        KEYLOOP_END_COUNT(cn)
+        __syncthreads();
+        OCT_T(7);
+        m = newM; lastBase = arenaN; lastC = C; arenaN += C; nAlive = nAliveNext; phaseB = phaseBnext;
         { uint32_t *t2 = cur; cur = nxt; nxt = t2; }
         { OrbxNode *t3 = lnA; lnA = lnB; lnB = t3; }
-        if (sh.done) break;
+        { uint32_t *t4 = cc; cc = cn; cn = t4; }
     }
 
     // ---- final selection (:743-762) ----
-    const int m = sh.m;
-    __syncthreads();
+    unsigned long long *best = reinterpret_cast<unsigned long long *>(cn);   // the idle counter buffer
+    OCT_T(8);
     for (int i = tid; i < m; i += T) {
         posOf[cur[i]] = i;
-        best[i] = 0ull;   // aliases cnt; child ids are no longer needed
+        best[i] = 0ull;
     }
     __threadfence_block();
     __syncthreads();
-    for (int k = tid; k < n; k += T) {
-        const uint32_t id = OWN(k) & OCT_ID_MASK;
-        const int pos = posOf[id];
-        const OrbxCand c = cand[k];
-        const int xa = (int)(c.xy & 0xFFFFu) - ORBX_EDGE, ya = (int)(c.xy >> 16) - ORBX_EDGE;
-        const int cr = ya / L.hCell, cc = xa / L.wCell;
-        const unsigned long long order = ((unsigned long long)cr << 24) | ((unsigned long long)cc << 12) |
-                                         ((unsigned long long)(ya - cr * L.hCell) << 6) |
-                                         (unsigned long long)(xa - cc * L.wCell);
-        const unsigned long long pack = ((unsigned long long)c.resp << 56) |
-                                        ((~order & 0xFFFFFFFFFull) << 20) | (unsigned long long)k;
-        atomicMax(&best[pos], pack);
+    for (int kb = 0; kb < n; kb += T * KU) {
+#pragma unroll
+        for (int u0 = 0; u0 < KU; u0 += 8) {      // 8 keys at a time: issue the loads, then the updates
+            if (kb + u0 * T >= n) break;
+            int posv[8];
+            uint32_t rv[8], xv[8];
+#pragma unroll
+            for (int j = 0; j < 8; j++) {
+                const int k = kb + (u0 + j) * T + tid;
+                if (u0 + j < KU && k < n) {
+                    const uint32_t own = REG ? wv[(u0 + j) % KU] : owner[k];
+                    posv[j] = posOf[own & OCT_ID_MASK];
+                    rv[j] = cand[k].resp;
+                    xv[j] = REG ? xyv[(u0 + j) % KU] : cand[k].xy;
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < 8; j++) {
+                const int k = kb + (u0 + j) * T + tid;
+                if (u0 + j < KU && k < n) {
+                    const int xa = (int)(xv[j] & 0xFFFFu) - ORBX_EDGE, ya = (int)(xv[j] >> 16) - ORBX_EDGE;
+                    const int cr = ya / L.hCell, ccol = xa / L.wCell;
+                    const unsigned long long order = ((unsigned long long)cr << 24) | ((unsigned long long)ccol << 12) |
+                                                     ((unsigned long long)(ya - cr * L.hCell) << 6) |
+                                                     (unsigned long long)(xa - ccol * L.wCell);
+                    const unsigned long long pack = ((unsigned long long)rv[j] << 56) |
+                                                    ((~order & 0xFFFFFFFFFull) << 20) | (unsigned long long)k;
+                    atomicMax(&best[posv[j]], pack);
+                }
+            }
+        }
     }
     __syncthreads();
     for (int i = tid; i < m; i += T) sel[i] = cand[(int)(best[i] & 0xFFFFFull)];
     if (tid == 0) wk.nk[f * plan.nlevels + l] = (uint32_t)m;
-#undef KXY
-#undef OWN
+    OCT_T(9);
+#ifdef OCT_TRACE
+    if (tid == 0 && blockIdx.x == 0 && blockIdx.y == 0) g_oct_trace[0] = (unsigned long long)tp | ((unsigned long long)n << 32);
+#endif
+#undef KEYLOOP_BEGIN
+#undef KEYLOOP_END
+#undef KEYLOOP_END_COUNT
+#undef SETOWN
 }
 
+// One workgroup = one (frame, level).
 template <int T>
 __global__ __launch_bounds__(T) void k_octree(OrbxPlan plan, OrbxWork wk)
 {
@@ -331,15 +479,14 @@ __global__ __launch_bounds__(T) void k_octree(OrbxPlan plan, OrbxWork wk)
     const int cap = L.list_cap;
     const int N = L.quota;
 
-    uint32_t *cnt = reinterpret_cast<uint32_t *>(oct_lds);                 // [4*cap]  counts, then child ids
-    uint32_t *listA = cnt + 4 * cap;                                       // [cap]
+    uint32_t *cnt0 = reinterpret_cast<uint32_t *>(oct_lds);                // [4*cap]  quadrant counts, then child ids
+    uint32_t *cnt1 = cnt0 + 4 * cap;                                       // [4*cap]  the other pass's counters
+    uint32_t *listA = cnt1 + 4 * cap;                                      // [cap]
     uint32_t *listB = listA + cap;                                         // [cap]
     uint32_t *slotNode = listB + cap;                                      // [cap]  slot -> index in the node window
     int *childBase = reinterpret_cast<int *>(slotNode + cap);              // [cap]
-    OrbxNode *lnA = reinterpret_cast<OrbxNode *>(childBase + cap);         // [cap]  node window (previous pass)
+    OrbxNode *lnA = reinterpret_cast<OrbxNode *>(childBase + cap);         // [cap]  node window
     OrbxNode *lnB = lnA + cap;                                             // [cap]  children of this pass
-    uint32_t *kxy = reinterpret_cast<uint32_t *>(lnB + cap);                 // [OCT_KEYCAP] candidate x | y << 16
-    uint32_t *kown = kxy + OCT_KEYCAP;                                       // [OCT_KEYCAP] key -> node id
 
     const OrbxCand *cand = wk.cand + (long long)f * plan.cand_frame + L.cand_off;
     uint32_t *owner = wk.owner + (long long)f * plan.cand_frame + L.cand_off;
@@ -351,18 +498,29 @@ __global__ __launch_bounds__(T) void k_octree(OrbxPlan plan, OrbxWork wk)
         wk.ncand[f * plan.nlevels + l] = (uint32_t)n;
         ORBX_CNT(wk, plan, f, l) = 0;
     }
-
     if (n == 0 || L.nIni <= 0) {
         if (tid == 0) wk.nk[f * plan.nlevels + l] = 0;
         return;
     }
-    if (n <= OCT_KEYCAP)
-        oct_body<T, true>(plan, wk, sh, L, f, l, n, cap, N, cnt, listA, listB, slotNode, childBase, lnA, lnB, kxy, kown, cand, owner, posOf, sel);
-    else
-        oct_body<T, false>(plan, wk, sh, L, f, l, n, cap, N, cnt, listA, listB, slotNode, childBase, lnA, lnB, kxy, kown, cand, owner, posOf, sel);
+#define OCT_ARGS plan, wk, sh, L, f, l, n, cap, N, cnt0, cnt1, listA, listB, slotNode, childBase, lnA, lnB, cand, owner, posOf, sel
+    // T = 512 serves the small shapes, many workgroups per CU: stay under 128 VGPRs.  T = 1024 owns its CU anyway.
+    if constexpr (T == 512) {
+        if (n <= 12 * T)
+            oct_body<T, 12>(OCT_ARGS);
+        else
+            oct_body<T, 0>(OCT_ARGS);
+    } else {
+        if (n <= 8 * T)
+            oct_body<T, 8>(OCT_ARGS);
+        else if (n <= 32 * T)
+            oct_body<T, 32>(OCT_ARGS);
+        else
+            oct_body<T, 0>(OCT_ARGS);
+    }
+#undef OCT_ARGS
 }
 
-size_t orbx_octree_lds_bytes(int list_cap_max) { return (size_t)list_cap_max * 64 + (size_t)OCT_KEYCAP * 8; }
+size_t orbx_octree_lds_bytes(int list_cap_max) { return (size_t)list_cap_max * 80; }
 
 void orbx_launch_octree(const OrbxPlan &plan, const OrbxWork &wk, int nframes, size_t lds_bytes, hipStream_t s)
 {
@@ -379,3 +537,10 @@ void orbx_launch_octree(const OrbxPlan &plan, const OrbxWork &wk, int nframes, s
         hipLaunchKernelGGL(k_octree<OCT_THREADS>, grid, dim3(OCT_THREADS), lds_bytes, s, plan, wk);
     }
 }
+
+#ifdef OCT_TRACE
+extern "C" int orbx_debug_oct_trace(unsigned long long *out)
+{
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_oct_trace), sizeof(unsigned long long) * 256);
+}
+#endif
