@@ -146,15 +146,23 @@ struct __attribute__((aligned(16))) DescLds {
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); \
     } while (0)
 
+ORBX_TRACE_DEFINE(g_desc_trace, orbx_debug_desc_trace)
+
 __global__ __launch_bounds__(256) void k_describe(
     OrbxPlan plan, OrbxWork wk, orbx_keypoint *__restrict__ kps, uint8_t *__restrict__ desc,
-    int32_t *__restrict__ counts, int32_t *__restrict__ status, int l0_aligned)
+    int32_t *__restrict__ counts, int32_t *__restrict__ status, int l0_aligned, int wg_per_frame, int nwg)
 {
     __shared__ DescLds lds[4];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int g = blockIdx.x * 4 + wave, f = blockIdx.y;
+    // XCD x (workgroups x, x + 8, ...) takes the x-th contiguous eighth of the (frame, keypoint) list: the patches of
+    // one frame overlap heavily, and its whole pyramid fits the XCD's L2.  Speed only; the padded grid keeps it a bijection.
+    const int lb = (int)(blockIdx.x & 7u) * (int)(gridDim.x >> 3) + (int)(blockIdx.x >> 3);
+    if (lb >= nwg) return;
+    const int f = lb / wg_per_frame;
+    const int g = (lb - f * wg_per_frame) * 4 + wave;
     DescLds &S = lds[wave];
+    ORBX_TRACE_DECL;
 
     int total = 0, l = -1, idx = 0;
     for (int i = 0; i < plan.nlevels; i++) {
@@ -212,6 +220,7 @@ __global__ __launch_bounds__(256) void k_describe(
         }
     }
     DSYNC();
+    ORBX_TRACE_STAMP(0);
 
     // ---- IC_Angle (:79-106): m10 = sum u*I, m01 = sum v*I over |u| <= umax[|v|] ----
     // dword tasks (row 0..30, dword 1..9 of the raw row); weights (u+32) keep the dot product unsigned
@@ -248,6 +257,7 @@ __global__ __launch_bounds__(256) void k_describe(
     }
     const float angle = fast_atan2_deg((float)m01, (float)m10);
 
+    ORBX_TRACE_STAMP(1);
     // ---- 7x7 Gaussian, row pass (exact, <= 65535), two rows per task, packed vertically ----
     const uint32_t k0 = (uint32_t)c_gauss[0], k1 = (uint32_t)c_gauss[1], k2 = (uint32_t)c_gauss[2], k3 = (uint32_t)c_gauss[3];
     const uint32_t KA = k0 | (k1 << 8) | (k2 << 16) | (k3 << 24);     // taps 0..3
@@ -274,6 +284,7 @@ __global__ __launch_bounds__(256) void k_describe(
         }
     }
     DSYNC();
+    ORBX_TRACE_STAMP(2);
 
     // ---- column pass: lane = (column pair, block of row pairs); 4 x dot2 per output ----
     uint8_t *bl = S.raw;   // raw is dead from here on
@@ -324,6 +335,7 @@ __global__ __launch_bounds__(256) void k_describe(
         }
     }
     DSYNC();
+    ORBX_TRACE_STAMP(3);
 
     // ---- rBRIEF (:110-149) ----
     const float factorPI = (float)(3.14159265358979323846 / 180.f);
@@ -364,6 +376,8 @@ __global__ __launch_bounds__(256) void k_describe(
         kp.class_id = -1;
         kps[o] = kp;
     }
+    ORBX_TRACE_STAMP(4);
+    ORBX_TRACE_FLUSH(g_desc_trace);
 }
 
 void orbx_launch_describe(const OrbxPlan &plan, const OrbxWork &wk, int nframes,
@@ -372,6 +386,8 @@ void orbx_launch_describe(const OrbxPlan &plan, const OrbxWork &wk, int nframes,
 {
     const OrbxLevel &L0 = plan.lv[0];
     const int l0_aligned = (((uintptr_t)L0.base | (uintptr_t)L0.stride | (uintptr_t)L0.frame_stride) & 3) == 0;
-    dim3 grid((plan.out_cap + 3) / 4, nframes);
-    hipLaunchKernelGGL(k_describe, grid, dim3(256), 0, s, plan, wk, d_kps, d_desc, d_counts, d_status, l0_aligned);
+    const int wg_per_frame = (plan.out_cap + 3) / 4;
+    const int nwg = wg_per_frame * nframes;
+    hipLaunchKernelGGL(k_describe, dim3((nwg + 7) & ~7), dim3(256), 0, s, plan, wk, d_kps, d_desc, d_counts, d_status, l0_aligned,
+                       wg_per_frame, nwg);
 }

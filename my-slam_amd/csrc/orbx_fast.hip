@@ -123,15 +123,28 @@ __device__ __forceinline__ void fast_stage2(const uint8_t *T0, const uint16_t *q
     if (two && s1 >= t_lo) { smap[((pb >> 6) + 1) * ZS + (pb & 63) + 1] = (uint8_t)s1; *c1 = true; }
 }
 
+ORBX_TRACE_DEFINE(g_fast_trace, orbx_debug_fast_trace)
+#define FT_DECL ORBX_TRACE_DECL
+#define FT(i) ORBX_TRACE_STAMP(i)
+#define FT_FLUSH ORBX_TRACE_FLUSH(g_fast_trace)
+
 template <int TS, int TH, int ZS>
-__global__ __launch_bounds__(FAST_THREADS) void k_fast_cells(OrbxPlan plan, OrbxWork wk, int l0_aligned, int cell_lo, int cell_hi)
+__global__ __launch_bounds__(FAST_THREADS) void k_fast_cells(OrbxPlan plan, OrbxWork wk, int l0_aligned, int cell_lo, int cell_hi,
+                                                             int wg_per_frame, int nwg)
 {
     __shared__ __attribute__((aligned(16))) FastLds<TS, TH, ZS> lds[FAST_THREADS / 64];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int cell = cell_lo + blockIdx.x * (FAST_THREADS / 64) + wave, f = blockIdx.y;
+    // Workgroups are dealt round-robin over the 8 XCDs (each with its own L2): give XCD x the x-th contiguous eighth
+    // of the (frame, cell) list, so that neighbouring cells -- which share their 6-pixel halos -- meet in one L2.
+    // The grid is padded to a multiple of 8, which makes the map a bijection.  Placement is for speed only.
+    const int lb = (int)(blockIdx.x & 7u) * (int)(gridDim.x >> 3) + (int)(blockIdx.x >> 3);
+    if (lb >= nwg) return;
+    const int f = lb / wg_per_frame;
+    const int cell = cell_lo + (lb - f * wg_per_frame) * (FAST_THREADS / 64) + wave;
     if (cell >= cell_hi) return;
     FastLds<TS, TH, ZS> &S = lds[wave];
+    FT_DECL;
 
     int l = 0;
     for (int i = 1; i < plan.nlevels; i++)
@@ -168,6 +181,7 @@ __global__ __launch_bounds__(FAST_THREADS) void k_fast_cells(OrbxPlan plan, Orbx
                     *reinterpret_cast<const uint32_t *>(src + (long long)r * L.stride);
         }
     }
+    FT(0);
     const uint8_t *T0 = S.tile + FAST_PADL + xoff;   // tile origin (cell column 0)
     const int cb = FAST_PADL + xoff + 3;             // tile byte column of zone column 0
     const int g0 = cb >> 2, ng = ((cb + zw - 1) >> 2) - g0 + 1;
@@ -179,7 +193,7 @@ __global__ __launch_bounds__(FAST_THREADS) void k_fast_cells(OrbxPlan plan, Orbx
     // survivor is redone at minThFAST (when that is lower -- a higher one cannot add anything).
     for (int pass = 0; pass < 2; pass++) {
         const int t_lo = pass == 0 ? plan.ini_th : plan.min_th;
-        if (pass == 1 && plan.min_th >= plan.ini_th) return;
+        if (pass == 1 && plan.min_th >= plan.ini_th) { FT_FLUSH; return; }
         {   // zero the score map (1-px zero ring = "outside the cell counts as 0")
             uint32_t *z = reinterpret_cast<uint32_t *>(S.smap);
             const int nz = (ZS * (zh + 2) + 3) >> 2;
@@ -251,7 +265,9 @@ __global__ __launch_bounds__(FAST_THREADS) void k_fast_cells(OrbxPlan plan, Orbx
             qn += n0 + n1 + n2 + __popcll(b3);
             while (qn >= 128) {
                 WSYNC();
+                FT(1);
                 DRAIN(128);
+                FT(2);
                 const int rest = qn - 128;            // move the tail of the queue to the front
                 WSYNC();
                 for (int i0 = 0; i0 < rest; i0 += 64) {   // rest < 256: ascending blocks never overwrite unread entries
@@ -265,9 +281,11 @@ __global__ __launch_bounds__(FAST_THREADS) void k_fast_cells(OrbxPlan plan, Orbx
             }
         }
         WSYNC();
+        FT(1);
         DRAIN(qn);   // the remaining survivors (qn < 128)
 #undef DRAIN
         WSYNC();
+        FT(2);
 
         // ---- stage 3: NMS (strictly greater than all 8 neighbours; outside the cell zone counts as 0).
         // Items are the listed corners, or every zone pixel if the list overflowed. ----
@@ -291,6 +309,7 @@ __global__ __launch_bounds__(FAST_THREADS) void k_fast_cells(OrbxPlan plan, Orbx
             if (lane == 0) S.masks[it] = mm;
             total += __popcll(mm);
         }
+        FT(3);
         if (total == 0) continue;   // nothing at this threshold: fall back to the lower one
 
         int gbase = 0;
@@ -319,8 +338,11 @@ __global__ __launch_bounds__(FAST_THREADS) void k_fast_cells(OrbxPlan plan, Orbx
             }
             written += __popcll(mm);
         }
+        FT(4);
+        FT_FLUSH;
         return;
     }
+    FT_FLUSH;
 }
 
 void orbx_launch_fast(const OrbxPlan &plan, const OrbxWork &wk, int nframes, int cell_lo, int cell_hi, hipStream_t s)
@@ -332,9 +354,11 @@ void orbx_launch_fast(const OrbxPlan &plan, const OrbxWork &wk, int nframes, int
         if (plan.lv[l].nCols > 0) maxcell = max(maxcell, max(plan.lv[l].wCell, plan.lv[l].hCell));
     const OrbxLevel &L0 = plan.lv[0];
     const int l0_aligned = (((uintptr_t)L0.base | (uintptr_t)L0.stride | (uintptr_t)L0.frame_stride) & 3) == 0;
-    dim3 grid((cell_hi - cell_lo + FAST_THREADS / 64 - 1) / (FAST_THREADS / 64), nframes);
+    const int wg_per_frame = (cell_hi - cell_lo + FAST_THREADS / 64 - 1) / (FAST_THREADS / 64);
+    const int nwg = wg_per_frame * nframes;
+    dim3 grid((nwg + 7) & ~7);
     if (maxcell <= 38)   // tile <= 44x44, zone <= 38x38; row = 4 pad + 3 + 44 + over-read -> 56 B
-        hipLaunchKernelGGL((k_fast_cells<56, 44, 40>), grid, dim3(FAST_THREADS), 0, s, plan, wk, l0_aligned, cell_lo, cell_hi);
+        hipLaunchKernelGGL((k_fast_cells<56, 44, 40>), grid, dim3(FAST_THREADS), 0, s, plan, wk, l0_aligned, cell_lo, cell_hi, wg_per_frame, nwg);
     else                 // cells of tiny levels: tile <= 66x66, zone <= 60x60
-        hipLaunchKernelGGL((k_fast_cells<80, 66, 64>), grid, dim3(FAST_THREADS), 0, s, plan, wk, l0_aligned, cell_lo, cell_hi);
+        hipLaunchKernelGGL((k_fast_cells<80, 66, 64>), grid, dim3(FAST_THREADS), 0, s, plan, wk, l0_aligned, cell_lo, cell_hi, wg_per_frame, nwg);
 }

@@ -2,6 +2,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <string.h>
 #include "../../include/orbx.h"
 
 #define ORBX_EDGE 19          // EDGE_THRESHOLD, src/ORBextractor.cc:76
@@ -16,6 +17,29 @@
 
 #ifndef OCT_THREADS
 #define OCT_THREADS 512
+
+// -DORBX_TRACE: per-phase shader-clock totals summed over all waves of a kernel (tools/dbg/phase_trace.py); slot 7 counts waves.
+#ifdef ORBX_TRACE
+#define ORBX_TRACE_DEFINE(SYM, FN)                                                                                      \
+    __device__ unsigned long long SYM[256 * 16];   /* 256 copies, 128 B apart: the flush must not serialise in L2 */   \
+    extern "C" int FN(unsigned long long *out, int reset)                                                               \
+    {                                                                                                                   \
+        static unsigned long long h[256 * 16];                                                                          \
+        if (reset) { for (int i = 0; i < 256 * 16; i++) h[i] = 0; return (int)hipMemcpyToSymbol(HIP_SYMBOL(SYM), h, sizeof(h)); }           \
+        const int rc = (int)hipMemcpyFromSymbol(h, HIP_SYMBOL(SYM), sizeof(h));                                         \
+        for (int i = 0; i < 8; i++) { out[i] = 0; for (int c = 0; c < 256; c++) out[i] += h[c * 16 + i]; }              \
+        return rc;                                                                                                      \
+    }
+#define ORBX_TRACE_DECL unsigned long long ft_last = __builtin_readcyclecounter(), ft_acc[6] = {0, 0, 0, 0, 0, 0}
+#define ORBX_TRACE_STAMP(i) do { const unsigned long long n_ = __builtin_readcyclecounter(); ft_acc[i] += n_ - ft_last; ft_last = n_; } while (0)
+#define ORBX_TRACE_FLUSH(SYM) do { if (lane == 0) { unsigned long long *t_ = &SYM[((blockIdx.x * 4 + (threadIdx.x >> 6)) & 255) * 16]; for (int i_ = 0; i_ < 6; i_++) atomicAdd(&t_[i_], ft_acc[i_]); atomicAdd(&t_[7], 1ull); } } while (0)
+#else
+#define ORBX_TRACE_DEFINE(SYM, FN)
+#define ORBX_TRACE_DECL
+#define ORBX_TRACE_STAMP(i) do { } while (0)
+#define ORBX_TRACE_FLUSH(SYM) do { } while (0)
+#endif
+
 #endif
 #define OCT_ID_MASK 0x3FFFFFFFu
 
