@@ -8,6 +8,7 @@
 #include <vector>
 
 #include "orbm_internal.h"
+#include "orbx_internal.h"
 
 // -------------------------------------------------------------------------------------------------
 // k_grid_build: one 1024-thread workgroup.  Count per cell (LDS atomics) -> scan -> scatter -> each
@@ -128,8 +129,8 @@ __global__ __launch_bounds__(M_THREADS) void k_area_list(OrbmGrid g, const float
                 int i = -1;
                 bool ok = false;
                 if (j < e) { i = g.items[j]; ok = in_window(g, i, x, y, r, mn, mx); }
-                const unsigned long long m = __ballot(ok);
-                if (MODE == 1 && ok) out[base + n + __popcll(m & ((1ull << lane) - 1ull))] = i;
+                const unsigned long long m = __builtin_amdgcn_ballot_w64(ok);
+                if (MODE == 1 && ok) out[orbx_prefix_cnt(m, base + n)] = i;
                 n += __popcll(m);
             }
         }
@@ -168,11 +169,11 @@ __global__ __launch_bounds__(M_THREADS) void k_search_area(OrbmGrid g, const uin
                     i = g.items[j];
                     ok = in_window(g, i, x, y, r, mn, mx) && !(skip && skip[i]);
                 }
-                const unsigned long long m = __ballot(ok);
+                const unsigned long long m = __builtin_amdgcn_ballot_w64(ok);
                 if (ok) {
                     const uint4 *Tj = reinterpret_cast<const uint4 *>(tdesc) + 2 * (long long)i;
                     const int d = hamming256(q0, q1, Tj[0], Tj[1]);
-                    const uint32_t p = ((uint32_t)d << 22) | (uint32_t)min(n + __popcll(m & ((1ull << lane) - 1ull)), 0x3FFFFF);
+                    const uint32_t p = ((uint32_t)d << 22) | (uint32_t)min(orbx_prefix_cnt(m, n), 0x3FFFFF);
                     if (p < bp) { s2 = (int)(bp >> 22); bp = p; bidx = i; }
                     else if (d < s2) s2 = d;
                 }

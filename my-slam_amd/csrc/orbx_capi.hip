@@ -59,6 +59,7 @@ struct orbx_extractor {
     uint8_t *d_input = nullptr; int in_stride = 0; size_t in_frame = 0;
     uint8_t *d_pyr = nullptr;
     int *d_tab_i = nullptr; short2 *d_tab_s = nullptr; size_t tab_elems = 0;
+    uint32_t *d_cells = nullptr; int cells_cap = 0;   // per-cell (level, row, column) table of the current plan
     orbx_keypoint *d_kps = nullptr; uint8_t *d_desc = nullptr; int32_t *d_counts = nullptr, *d_status = nullptr;
     uint8_t *h_in = nullptr;
     orbx_keypoint *h_kps = nullptr; uint8_t *h_desc = nullptr; int32_t *h_counts = nullptr, *h_status = nullptr;
@@ -181,7 +182,7 @@ static void free_all(orbx_extractor *h)
 {
     if (!h) return;
     hipSetDevice(h->device);
-    hipFree(h->d_input); hipFree(h->d_pyr); hipFree(h->d_tab_i); hipFree(h->d_tab_s);
+    hipFree(h->d_input); hipFree(h->d_pyr); hipFree(h->d_tab_i); hipFree(h->d_tab_s); hipFree(h->d_cells);
     hipFree(h->work.cand); hipFree(h->work.cand_count); hipFree(h->work.owner); hipFree(h->work.arena);
     hipFree(h->work.sel); hipFree(h->work.nk); hipFree(h->work.ncand); hipFree(h->work.errflags);
     hipFree(h->d_kps); hipFree(h->d_desc); hipFree(h->d_counts); hipFree(h->d_status);
@@ -244,6 +245,8 @@ extern "C" int orbx_create(orbx_extractor **out, int nfeatures, float scale_fact
     ALLOC(h->d_pyr, off + 256);   // slack: the 4x4 resize reads whole dwords around a row segment
     ALLOC(h->d_tab_i, tab_e * sizeof(int));
     ALLOC(h->d_tab_s, tab_e * sizeof(short2));
+    h->cells_cap = h->max_plan.ncells + 64 * nlevels;   // a smaller frame never has more cells; slack for rounding
+    ALLOC(h->d_cells, (size_t)h->cells_cap * sizeof(uint32_t));
     const OrbxPlan &M = h->max_plan;
     ALLOC(h->work.cand, B * M.cand_frame * sizeof(OrbxCand));
     ALLOC(h->work.owner, B * M.cand_frame * sizeof(uint32_t));
@@ -350,7 +353,17 @@ static int ensure_plan(orbx_extractor *h, int W, int H)
         h->tabs[l].yofs = h->d_tab_i + e + ex; h->tabs[l].beta = h->d_tab_s + e + ex;
         e += ex + ey;
     }
+    if (P.ncells > h->cells_cap) return fail(ORBX_E_SHAPE, "frame %dx%d has more FAST cells than the workspace planned for %dx%d", W, H, h->max_w, h->max_h);
+    std::vector<uint32_t> cells((size_t)std::max(P.ncells, 1));
+    for (int l = 0; l < h->nlevels; l++) {
+        const OrbxLevel &L = P.lv[l];
+        if (L.nRows >= 4096 || L.nCols >= 4096) return fail(ORBX_E_SHAPE, "level %d has too many FAST cells", l);
+        for (int i = 0; i < L.nRows; i++)
+            for (int j = 0; j < L.nCols; j++) cells[(size_t)L.cell_begin + (size_t)i * L.nCols + j] = (uint32_t)l | ((uint32_t)i << 4) | ((uint32_t)j << 16);
+    }
+    P.cell_tab = h->d_cells;
     HIPCHK(hipStreamSynchronize(h->stream));
+    HIPCHK(hipMemcpy(h->d_cells, cells.data(), (size_t)P.ncells * sizeof(uint32_t), hipMemcpyHostToDevice));
     HIPCHK(hipMemcpy(h->d_tab_i, ti.data(), e * sizeof(int), hipMemcpyHostToDevice));
     HIPCHK(hipMemcpy(h->d_tab_s, ts.data(), e * sizeof(short2), hipMemcpyHostToDevice));
     h->plan = P;

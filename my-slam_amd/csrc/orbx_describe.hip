@@ -354,7 +354,7 @@ __global__ __launch_bounds__(256) void k_describe(
         const int q1 = __float2int_rn(__fsub_rn(__fmul_rn(px1, a), __fmul_rn(py1, b)));
         const int t0 = bl[(DESC_R + r0) * DW_BL_STRIDE + DESC_R + q0];
         const int t1 = bl[(DESC_R + r1) * DW_BL_STRIDE + DESC_R + q1];
-        bits[j] = __ballot(t0 < t1);
+        bits[j] = __builtin_amdgcn_ballot_w64(t0 < t1);
     }
     const long long o = (long long)f * plan.out_cap + g;
     if (lane < 4) {

@@ -84,8 +84,8 @@ __device__ __forceinline__ void fast_stage2(const uint8_t *T0, const uint16_t *q
     const bool two = lane + 64 < cnt;
     const int pa = queue[lane], pb = two ? queue[lane + 64] : pa;
     *pos0 = pa; *pos1 = pb;
-    const uint8_t *p = T0 + ((pa >> 6) + 3) * TS + (pa & 63) + 3;
-    const uint8_t *q = T0 + ((pb >> 6) + 3) * TS + (pb & 63) + 3;
+    const uint8_t *p = T0 + __umul24((uint32_t)(pa >> 6) + 3u, (uint32_t)TS) + (pa & 63) + 3;
+    const uint8_t *q = T0 + __umul24((uint32_t)(pb >> 6) + 3u, (uint32_t)TS) + (pb & 63) + 3;
     const ss2 v = pk(p[0], q[0]);
     ss2 d[16];
     d[0] = v - pk(p[3 * TS], q[3 * TS]);            d[1] = v - pk(p[3 * TS + 1], q[3 * TS + 1]);
@@ -119,9 +119,17 @@ __device__ __forceinline__ void fast_stage2(const uint8_t *T0, const uint16_t *q
     }
     const ss2 sc = __builtin_elementwise_max(A, -B) - pk(1, 1);   // <= 254
     const int s0 = sc.x, s1 = sc.y;
-    if (s0 >= t_lo) { smap[((pa >> 6) + 1) * ZS + (pa & 63) + 1] = (uint8_t)s0; *c0 = true; }
-    if (two && s1 >= t_lo) { smap[((pb >> 6) + 1) * ZS + (pb & 63) + 1] = (uint8_t)s1; *c1 = true; }
+    if (s0 >= t_lo) { smap[__umul24((uint32_t)(pa >> 6) + 1u, (uint32_t)ZS) + (pa & 63) + 1] = (uint8_t)s0; *c0 = true; }
+    if (two && s1 >= t_lo) { smap[__umul24((uint32_t)(pb >> 6) + 1u, (uint32_t)ZS) + (pb & 63) + 1] = (uint8_t)s1; *c1 = true; }
 }
+
+// (1 << 20) / n + 1 for n = 1..64 ([0] unused): division of small indices by a wave-uniform n without the
+// ~25-instruction integer-division expansion
+__constant__ uint32_t c_rcp20[65] = {
+    0, 1048577, 524289, 349526, 262145, 209716, 174763, 149797, 131073, 116509, 104858, 95326, 87382, 80660, 74899, 69906,
+    65537, 61681, 58255, 55189, 52429, 49933, 47663, 45591, 43691, 41944, 40330, 38837, 37450, 36158, 34953, 33826,
+    32769, 31776, 30841, 29960, 29128, 28340, 27595, 26887, 26215, 25576, 24967, 24386, 23832, 23302, 22796, 22311,
+    21846, 21400, 20972, 20561, 20165, 19785, 19419, 19066, 18725, 18397, 18079, 17773, 17477, 17190, 16913, 16645, 16385};
 
 ORBX_TRACE_DEFINE(g_fast_trace, orbx_debug_fast_trace)
 #define FT_DECL ORBX_TRACE_DECL
@@ -146,19 +154,16 @@ __global__ __launch_bounds__(FAST_THREADS) void k_fast_cells(OrbxPlan plan, Orbx
     FastLds<TS, TH, ZS> &S = lds[wave];
     FT_DECL;
 
-    int l = 0;
-    for (int i = 1; i < plan.nlevels; i++)
-        if (cell >= plan.lv[i].cell_begin) l = i;
+    const uint32_t ce = __builtin_amdgcn_readfirstlane(plan.cell_tab[cell]);   // one scalar load instead of a level search and a division
+    const int l = (int)(ce & 15u), ci = (int)((ce >> 4) & 0xFFFu), cj = (int)(ce >> 16);
     const OrbxLevel &L = plan.lv[l];
-    const int c = cell - L.cell_begin;
-    const int ci = c / L.nCols, cj = c - ci * L.nCols;
     const int iniX = ORBX_MINB + cj * L.wCell, iniY = ORBX_MINB + ci * L.hCell;
     const int tw = min(iniX + L.wCell + 6, L.maxBX) - iniX;
     const int th = min(iniY + L.hCell + 6, L.maxBY) - iniY;
     const int zw = tw - 6, zh = th - 6;
     if (zw <= 0 || zh <= 0) return;
     const int npx = zw * zh;
-    const uint32_t rcp = (1u << 20) / (uint32_t)zw + 1u;   // idx / zw == (idx * rcp) >> 20 for idx < 4096, zw < 64
+    const uint32_t rcp = c_rcp20[zw];   // (1 << 20) / zw + 1:  idx / zw == (idx * rcp) >> 20 for idx < 4096, zw < 64
 
     // ---- tile -> LDS.  Rows start at a 4-byte aligned address of the level (levels >= 1 always;
     // level 0 when the caller's base/strides are 4-byte multiples), so whole dwords are moved. ----
@@ -173,7 +178,9 @@ __global__ __launch_bounds__(FAST_THREADS) void k_fast_cells(OrbxPlan plan, Orbx
     } else {
         constexpr int NDW = TS / 4 - 2, RPP = 64 / NDW;   // payload dwords per tile row, rows per pass
         const int ndw = (xoff + tw + 3) >> 2;
-        const int r_in = lane / NDW, cdw = lane - r_in * NDW;
+        static_assert(NDW == 12 || NDW == 18, "lane / NDW below is written for these");
+        const int r_in = NDW == 12 ? (int)(__umul24((uint32_t)lane, 43u) >> 9) : (int)(__umul24((uint32_t)lane, 57u) >> 10);   // lane / NDW, lane < 64
+        const int cdw = lane - r_in * NDW;
         const uint8_t *src = img + (iniX & ~3) + 4 * cdw;
         if (r_in < RPP && cdw < ndw) {
             for (int r = r_in; r < th; r += RPP)
@@ -185,7 +192,7 @@ __global__ __launch_bounds__(FAST_THREADS) void k_fast_cells(OrbxPlan plan, Orbx
     const uint8_t *T0 = S.tile + FAST_PADL + xoff;   // tile origin (cell column 0)
     const int cb = FAST_PADL + xoff + 3;             // tile byte column of zone column 0
     const int g0 = cb >> 2, ng = ((cb + zw - 1) >> 2) - g0 + 1;
-    const uint32_t rcpg = (1u << 16) / (uint32_t)ng + 1u;    // t / ng for t < 1024, ng <= 16
+    const uint32_t rcpg = (c_rcp20[ng] + 15u) >> 4;          // (1 << 16) / ng + 1 (or one more): t / ng for t < 1024, ng <= 16
     const int ntask = ng * zh;
 
     // The reference calls FAST at iniThFAST and, only when that cell yields nothing, again at
@@ -209,19 +216,19 @@ __global__ __launch_bounds__(FAST_THREADS) void k_fast_cells(OrbxPlan plan, Orbx
     do {                                                                                                             \
         bool c0_, c1_; int p0_ = 0, p1_ = 0;                                                                         \
         fast_stage2<TS, ZS>(T0, S.queue, S.smap, (CNT), lane, t_lo, &c0_, &c1_, &p0_, &p1_);                         \
-        const unsigned long long m0_ = __ballot(c0_), m1_ = __ballot(c1_);                                           \
+        const unsigned long long m0_ = __builtin_amdgcn_ballot_w64(c0_), m1_ = __builtin_amdgcn_ballot_w64(c1_);                                           \
         const int n0_ = __popcll(m0_), n1_ = __popcll(m1_);                                                          \
         if (ncl + n0_ + n1_ <= FAST_CLIST) {                                                                         \
-            if (c0_) S.clist[ncl + __popcll(m0_ & ((1ull << lane) - 1ull))] = (uint16_t)p0_;                         \
-            if (c1_) S.clist[ncl + n0_ + __popcll(m1_ & ((1ull << lane) - 1ull))] = (uint16_t)p1_;                   \
+            if (c0_) S.clist[orbx_prefix_cnt(m0_, ncl)] = (uint16_t)p0_;                         \
+            if (c1_) S.clist[orbx_prefix_cnt(m1_, ncl + n0_)] = (uint16_t)p1_;                   \
             ncl += n0_ + n1_;                                                                                        \
         } else cl_over = true;                                                                                       \
     } while (0)
         for (int base = 0; base < ntask; base += 64) {
             // lanes past the last task redo the last one; their pixels are masked out through zx0
             const int t = min(base + lane, ntask - 1);
-            const int zy = (int)(((uint32_t)t * rcpg) >> 16);
-            const int g = g0 + (t - zy * ng);
+            const int zy = (int)(__umul24((uint32_t)t, rcpg) >> 16);
+            const int g = g0 + (t - (int)__umul24((uint32_t)zy, (uint32_t)ng));
             const int zx0 = (base + lane < ntask) ? 4 * g - cb : -1000;   // zone column of byte 0 of this group
             uint32_t f01, f23;
             {
@@ -248,15 +255,20 @@ __global__ __launch_bounds__(FAST_THREADS) void k_fast_cells(OrbxPlan plan, Orbx
 #endif
             }
             // append the survivors of the 4 pixels: four ballots, one queue update (entry order is free)
-            const bool k0 = (f01 & 0x0000FFFFu) != 0 && zx0 >= 0 && zx0 < zw;
-            const bool k1 = (f01 & 0xFFFF0000u) != 0 && zx0 + 1 >= 0 && zx0 + 1 < zw;
-            const bool k2 = (f23 & 0x0000FFFFu) != 0 && zx0 + 2 >= 0 && zx0 + 2 < zw;
-            const bool k3 = (f23 & 0xFFFF0000u) != 0 && zx0 + 3 >= 0 && zx0 + 3 < zw;
-            const unsigned long long b0 = __ballot(k0), b1 = __ballot(k1), b2 = __ballot(k2), b3 = __ballot(k3);
-            const unsigned long long lt = (1ull << lane) - 1ull;
+            // (each ballot is taken straight from a compare and combined on the scalar unit; a ballot of a combined
+            // predicate costs two more vector instructions)
+            const bool f0 = (f01 & 0x0000FFFFu) != 0, f1 = (f01 & 0xFFFF0000u) != 0;
+            const bool f2 = (f23 & 0x0000FFFFu) != 0, f3 = (f23 & 0xFFFF0000u) != 0;
+            const bool l0 = zx0 >= 0, l1 = zx0 >= -1, l2 = zx0 >= -2, l3 = zx0 >= -3;
+            const bool h0 = zx0 < zw, h1 = zx0 < zw - 1, h2 = zx0 < zw - 2, h3 = zx0 < zw - 3;
+            const bool k0 = f0 && l0 && h0, k1 = f1 && l1 && h1, k2 = f2 && l2 && h2, k3 = f3 && l3 && h3;
+#define BAL(P) __builtin_amdgcn_ballot_w64(P)
+            const unsigned long long b0 = BAL(f0) & BAL(l0) & BAL(h0), b1 = BAL(f1) & BAL(l1) & BAL(h1);
+            const unsigned long long b2 = BAL(f2) & BAL(l2) & BAL(h2), b3 = BAL(f3) & BAL(l3) & BAL(h3);
+#undef BAL
             const int n0 = __popcll(b0), n1 = __popcll(b1), n2 = __popcll(b2);
-            const int e0 = qn + __popcll(b0 & lt), e1 = qn + n0 + __popcll(b1 & lt);
-            const int e2 = qn + n0 + n1 + __popcll(b2 & lt), e3 = qn + n0 + n1 + n2 + __popcll(b3 & lt);
+            const int e0 = orbx_prefix_cnt(b0, qn), e1 = orbx_prefix_cnt(b1, qn + n0);
+            const int e2 = orbx_prefix_cnt(b2, qn + n0 + n1), e3 = orbx_prefix_cnt(b3, qn + n0 + n1 + n2);
             const int pz = (zy << 6) + zx0;          // (zy << 6) | zx for every pixel with 0 <= zx < 64
             S.queue[k0 ? e0 : 391] = (uint16_t)pz;
             S.queue[k1 ? e1 : 391] = (uint16_t)(pz + 1);
@@ -297,15 +309,15 @@ __global__ __launch_bounds__(FAST_THREADS) void k_fast_cells(OrbxPlan plan, Orbx
             bool ismax = false;
             if (idx < nitem) {
                 int y, x;
-                if (cl_over) { y = (int)(((uint32_t)idx * rcp) >> 20); x = idx - y * zw; }
+                if (cl_over) { y = (int)(__umul24((uint32_t)idx, rcp) >> 20); x = idx - (int)__umul24((uint32_t)y, (uint32_t)zw); }
                 else { const int pos = S.clist[idx]; y = pos >> 6; x = pos & 63; }
-                const uint8_t *q = &S.smap[(y + 1) * ZS + x + 1];
+                const uint8_t *q = &S.smap[__umul24((uint32_t)y + 1u, (uint32_t)ZS) + x + 1];
                 const int s = q[0];
                 if (s > 0)
                     ismax = s > q[-1] && s > q[1] && s > q[-ZS - 1] && s > q[-ZS] && s > q[-ZS + 1] &&
                             s > q[ZS - 1] && s > q[ZS] && s > q[ZS + 1];
             }
-            const unsigned long long mm = __ballot(ismax);
+            const unsigned long long mm = __builtin_amdgcn_ballot_w64(ismax);
             if (lane == 0) S.masks[it] = mm;
             total += __popcll(mm);
         }
@@ -324,13 +336,13 @@ __global__ __launch_bounds__(FAST_THREADS) void k_fast_cells(OrbxPlan plan, Orbx
             const int idx = it * 64 + lane;
             if ((mm >> lane) & 1ull) {
                 int y, x;
-                if (cl_over) { y = (int)(((uint32_t)idx * rcp) >> 20); x = idx - y * zw; }
+                if (cl_over) { y = (int)(__umul24((uint32_t)idx, rcp) >> 20); x = idx - (int)__umul24((uint32_t)y, (uint32_t)zw); }
                 else { const int pos = S.clist[idx]; y = pos >> 6; x = pos & 63; }
-                const int o = gbase + written + __popcll(mm & ((1ull << lane) - 1ull));
+                const int o = orbx_prefix_cnt(mm, gbase + written);
                 if (o < L.cand_cap) {
                     OrbxCand cnd;
                     cnd.xy = (uint32_t)(iniX + 3 + x) | ((uint32_t)(iniY + 3 + y) << 16);
-                    cnd.resp = (uint32_t)S.smap[(y + 1) * ZS + x + 1];
+                    cnd.resp = (uint32_t)S.smap[__umul24((uint32_t)y + 1u, (uint32_t)ZS) + x + 1];
                     out[o] = cnd;
                 } else {
                     atomicOr(&wk.errflags[f], (uint32_t)ERRF_CAND_OVERFLOW);

@@ -18,6 +18,14 @@
 #ifndef OCT_THREADS
 #define OCT_THREADS 512
 
+#ifdef __HIPCC__
+// base + number of set bits of mask below this lane: v_mbcnt_lo + v_mbcnt_hi (two instructions, base folded in)
+__device__ __forceinline__ int orbx_prefix_cnt(unsigned long long mask, int base)
+{
+    return (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, (uint32_t)base));
+}
+#endif
+
 // -DORBX_TRACE: per-phase shader-clock totals summed over all waves of a kernel (tools/dbg/phase_trace.py); slot 7 counts waves.
 #ifdef ORBX_TRACE
 #define ORBX_TRACE_DEFINE(SYM, FN)                                                                                      \
@@ -85,6 +93,7 @@ struct OrbxPlan {
     long long cand_frame;         // candidates per frame (elements)
     long long list_frame;         // sel entries per frame
     long long arena_frame;        // arena nodes per frame
+    const uint32_t *cell_tab;     // [ncells] level | cell row << 4 | cell column << 16 (device)
     OrbxLevel lv[ORBX_MAX_LEVELS];
 };
 

@@ -93,7 +93,7 @@ __device__ __forceinline__ void wave_count(uint32_t *ctr, int idx)
     const int lane = (int)__lane_id();
     const int prev = __shfl_up(idx, 1);
     const bool head = lane == 0 || prev != idx;
-    const unsigned long long hm = __ballot(head);
+    const unsigned long long hm = __builtin_amdgcn_ballot_w64(head);
     if (head && idx >= 0) {
         const unsigned long long rest = (hm >> lane) >> 1;
         const int len = rest ? __ffsll((long long)rest) : 64 - lane;
@@ -137,11 +137,11 @@ __device__ __forceinline__ int oct_assign_slots(OrbxNode *ln, int cntN, bool for
     for (int base = 0; base < cntN; base += T) {
         const int j = base + tid;
         const int c = j < cntN ? ln[j].count : 0;
-        const unsigned long long am = __ballot(c > 1);
+        const unsigned long long am = __builtin_amdgcn_ballot_w64(c > 1);
         int wbase = 0;
         if (__lane_id() == 0 && am) wbase = atomicAdd(&sh.nAlive, __popcll(am));
         wbase = __shfl(wbase, 0);
-        if (c > 1) keys[wbase + __popcll(am & ((1ull << __lane_id()) - 1ull))] = ((uint32_t)c << 12) | (uint32_t)j;
+        if (c > 1) keys[orbx_prefix_cnt(am, wbase)] = ((uint32_t)c << 12) | (uint32_t)j;
     }
     __syncthreads();
     const int nA = sh.nAlive;
