@@ -123,6 +123,8 @@ static int make_plan(const orbx_extractor *h, int W, int H, OrbxPlan *P, std::st
         L.nRows = height > 0 ? (int)(height / 30.f) : 0;
         if (L.nCols <= 0 || L.nRows <= 0) { L.nCols = L.nRows = 0; L.wCell = L.hCell = 1; }   // no cell => no keypoint
         else { L.wCell = (int)ceilf(width / L.nCols); L.hCell = (int)ceilf(height / L.nRows); }
+        L.rcpW = L.wCell > 1 ? (uint32_t)((1ull << 32) / (unsigned)L.wCell + 1) : 0u;
+        L.rcpH = L.hCell > 1 ? (uint32_t)((1ull << 32) / (unsigned)L.hCell + 1) : 0u;
         L.cell_begin = cells;
         cells += L.nCols * L.nRows;
         L.quota = h->quota[l];
@@ -473,6 +475,9 @@ extern "C" int orbx_extract_batch_device(orbx_extractor *h, const uint8_t *d_ima
     if (!d_images || !d_keypoints || !d_descriptors || !d_counts || !d_status) return fail(ORBX_E_INVALID, "NULL device pointer");
     if (nframes < 1 || nframes > h->max_batch) return fail(ORBX_E_INVALID, "nframes=%d (max_batch=%d)", nframes, h->max_batch);
     if (width < 1 || height < 1 || row_stride < width) return fail(ORBX_E_INVALID, "bad frame geometry %dx%d stride %d", width, height, row_stride);
+    // the kernels index one frame with 31-bit byte offsets and 24-bit row strides
+    if (row_stride >= (1 << 23) || (long long)height * row_stride >= (1ll << 31))
+        return fail(ORBX_E_SHAPE, "frame %dx%d with row stride %d: one frame must be below 2 GiB, the stride below 8 MiB", width, height, row_stride);
     if (cap != h->max_plan.out_cap) return fail(ORBX_E_CAPACITY, "device outputs must be laid out with cap == orbx_capacity() == %d (got %d)", h->max_plan.out_cap, cap);
     HIPCHK(hipSetDevice(h->device));
     hipStream_t s = hip_stream ? (hipStream_t)hip_stream : h->stream;

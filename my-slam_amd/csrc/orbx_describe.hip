@@ -198,12 +198,14 @@ __global__ __launch_bounds__(256) void k_describe(
     if (fast) {
         const int xo = x0 & 3;
         const int rr = lane / 12, d = lane - rr * 12;     // 5 rows per pass, 12 dwords per row
-        const uint8_t *src = img + (long long)(y0 + rr) * L.stride + (x0 & ~3) + 4 * d;
+        // byte offsets inside one frame fit 31 bits; one 24-bit multiply per lane, the row steps are scalar
+        const uint8_t *src = img + (__mul24(y0 + rr, L.stride) + (x0 & ~3) + 4 * d);
+        const int step5 = 5 * L.stride;
         uint32_t gv[9];
 #pragma unroll
         for (int p = 0; p < 9; p++) {
             const int r = p * 5 + rr;
-            gv[p] = (lane < 60 && r < 43) ? *reinterpret_cast<const uint32_t *>(src + (long long)(p * 5) * L.stride) : 0u;
+            gv[p] = (lane < 60 && r < 43) ? *reinterpret_cast<const uint32_t *>(src + p * step5) : 0u;
         }
 #pragma unroll
         for (int p = 0; p < 9; p++) {
@@ -241,12 +243,12 @@ __global__ __launch_bounds__(256) void k_describe(
                 const uint32_t mhi = nhi >= 4 ? 0u : (0xFFFFFFFFu >> (8 * nhi));
                 const uint32_t msk = mlo & mhi;
                 // byte j holds u + 32 = (c0 + j - 21) + 32 = c0 + j + 11  (15..50: no carry between bytes)
-                const uint32_t wfull = (uint32_t)(c0 + 11) * 0x01010101u + 0x03020100u;
+                const uint32_t wfull = __builtin_amdgcn_perm(0u, (uint32_t)(c0 + 11), 0x00000000u) + 0x03020100u;   // byte broadcast (v_perm), not a 32-bit multiply
                 const uint32_t pix = *reinterpret_cast<const uint32_t *>(&S.raw[(6 + vr) * DW_RAW_STRIDE + c0]);
                 const int sA = (int)__builtin_amdgcn_udot4(pix, wfull & msk, 0u, false);
                 const int sB = (int)__builtin_amdgcn_udot4(pix, 0x01010101u & msk, 0u, false);
                 m10 += sA - 32 * sB;
-                m01 += v * sB;
+                m01 += __mul24(v, sB);
             }
         }
 #pragma unroll
@@ -352,8 +354,8 @@ __global__ __launch_bounds__(256) void k_describe(
         const int q0 = __float2int_rn(__fsub_rn(__fmul_rn(px0, a), __fmul_rn(py0, b)));
         const int r1 = __float2int_rn(__fadd_rn(__fmul_rn(px1, b), __fmul_rn(py1, a)));
         const int q1 = __float2int_rn(__fsub_rn(__fmul_rn(px1, a), __fmul_rn(py1, b)));
-        const int t0 = bl[(DESC_R + r0) * DW_BL_STRIDE + DESC_R + q0];
-        const int t1 = bl[(DESC_R + r1) * DW_BL_STRIDE + DESC_R + q1];
+        const int t0 = bl[__mul24(DESC_R + r0, DW_BL_STRIDE) + DESC_R + q0];
+        const int t1 = bl[__mul24(DESC_R + r1, DW_BL_STRIDE) + DESC_R + q1];
         bits[j] = __builtin_amdgcn_ballot_w64(t0 < t1);
     }
     const long long o = (long long)f * plan.out_cap + g;

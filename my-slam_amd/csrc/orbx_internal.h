@@ -73,6 +73,7 @@ struct OrbxLevel {
     uint8_t *base;                // frame 0 of this level (level 0: the caller's image)
     int maxBX, maxBY;             // w-16, h-16
     int nCols, nRows, wCell, hCell;
+    uint32_t rcpW, rcpH;          // floor(2^32 / wCell) + 1, same for hCell (0 when the cell size is 1): n / cell = umulhi(n, rcp), n < 2^16
     int cell_begin;               // index of this level's first cell in the per-frame cell list
     int quota;                    // mnFeaturesPerLevel[level]
     int nIni;                     // DistributeOctTree root count

@@ -443,10 +443,11 @@ __device__ __forceinline__ void oct_body(const OrbxPlan &plan, const OrbxWork &w
                 const int k = kb + (u0 + j) * T + tid;
                 if (u0 + j < KU && k < n) {
                     const int xa = (int)(xv[j] & 0xFFFFu) - ORBX_EDGE, ya = (int)(xv[j] >> 16) - ORBX_EDGE;
-                    const int cr = ya / L.hCell, ccol = xa / L.wCell;
+                    // exact for ya, xa < 2^16 (level sizes are capped there): one multiply instead of an integer division
+                    const int cr = L.rcpH ? (int)__umulhi((uint32_t)ya, L.rcpH) : ya, ccol = L.rcpW ? (int)__umulhi((uint32_t)xa, L.rcpW) : xa;
                     const unsigned long long order = ((unsigned long long)cr << 24) | ((unsigned long long)ccol << 12) |
-                                                     ((unsigned long long)(ya - cr * L.hCell) << 6) |
-                                                     (unsigned long long)(xa - ccol * L.wCell);
+                                                     ((unsigned long long)(ya - __mul24(cr, L.hCell)) << 6) |
+                                                     (unsigned long long)(xa - __mul24(ccol, L.wCell));
                     const unsigned long long pack = ((unsigned long long)rv[j] << 56) |
                                                     ((~order & 0xFFFFFFFFFull) << 20) | (unsigned long long)k;
                     atomicMax(&best[posv[j]], pack);

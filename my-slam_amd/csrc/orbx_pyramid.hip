@@ -97,7 +97,7 @@ __global__ __launch_bounds__(256) void k_resize_linear_4x4(
         const int sy0 = min(max(sy, 0), sh - 1), sy1 = min(max(sy + 1, 0), sh - 1);
 #pragma unroll
         for (int rr = 0; rr < 2; rr++) {
-            const uint8_t *p = S + (long long)(rr ? sy1 : sy0) * sstride + base;
+            const uint8_t *p = S + (__mul24(rr ? sy1 : sy0, sstride) + base);   // offsets inside a frame fit 31 bits; 24-bit multiply is full rate
             sh8[r][rr] = (uint32_t)((uintptr_t)p & 3u);
             const uint32_t *q = reinterpret_cast<const uint32_t *>(p - sh8[r][rr]);
             if (CHECK) {
@@ -131,10 +131,11 @@ __global__ __launch_bounds__(256) void k_resize_linear_4x4(
         uint32_t out = 0;
 #pragma unroll
         for (int i = 0; i < 4; i++) {
-            const int v = (((b0 * (hv[0][i] >> 4)) >> 16) + ((b1 * (hv[1][i] >> 4)) >> 16) + 2) >> 2;
+            // beta <= 2048 and (horizontal sum >> 4) <= 32640: exact in the full-rate 24-bit multiply
+            const int v = ((__mul24(b0, hv[0][i] >> 4) >> 16) + (__mul24(b1, hv[1][i] >> 4) >> 16) + 2) >> 2;
             out |= (uint32_t)(v & 255) << (8 * i);
         }
-        uint8_t *Dr = D + (long long)y * dstride + x4;
+        uint8_t *Dr = D + (__mul24(y, dstride) + x4);
         if (x4 + 3 < dw) *reinterpret_cast<uint32_t *>(Dr) = out;
         else
             for (int i = 0; x4 + i < dw; i++) Dr[i] = (uint8_t)(out >> (8 * i));
