@@ -4,10 +4,18 @@
 // with -ffp-contract=off.
 #include "orbx_internal.h"
 #include "orb_pattern_data.h"
+#include <algorithm>
+#define DW_RAW_STRIDE_H 48   // = DW_RAW_STRIDE below (host-side table builder)
 
 __constant__ unsigned long long c_umax_nib;   // umax[v] in nibble v (v = 0..15)
 __constant__ int c_gauss[7];
 __constant__ signed char c_pattern[1024];
+// Per-task constants of the IC_Angle dword tasks (t = row * 9 + dword - 1, 31 rows x 9 dwords, padded to 320):
+//   x = weights (u + 32 per byte, 0 outside the disc), y = 1 per byte inside the disc, z = byte offset of the dword in
+//   the raw tile, w = v (row offset, -15..15).  Replaces ~20 instructions of mask arithmetic per task.
+__constant__ uint4 c_mom_tab[320];
+// rBRIEF sample pairs as floats: (x0, y0, x1, y1) of bit b -- the int8 -> float conversions done once on the host
+__constant__ float4 c_pat_f[256];
 
 int orbx_upload_constants(const int umax[16], const int gauss_k[7])
 {
@@ -19,6 +27,26 @@ int orbx_upload_constants(const int umax[16], const int gauss_k[7])
     if (hipMemcpyToSymbol(HIP_SYMBOL(c_umax_nib), &nib, sizeof(nib)) != hipSuccess) return -1;
     if (hipMemcpyToSymbol(HIP_SYMBOL(c_gauss), gauss_k, sizeof(int) * 7) != hipSuccess) return -1;
     if (hipMemcpyToSymbol(HIP_SYMBOL(c_pattern), ORBX_PATTERN, 1024) != hipSuccess) return -1;
+    static uint4 mt[320];
+    for (int t = 0; t < 320; t++) {
+        mt[t] = make_uint4(0u, 0u, 0u, 0u);
+        if (t >= 31 * 9) continue;
+        const int vr = t / 9, dw = t - vr * 9 + 1, v = vr - 15;
+        const int um = umax[v < 0 ? -v : v];
+        const int lo = 21 - um, hi = 21 + um, c0 = 4 * dw;                  // valid raw columns; first column of this dword
+        const int nlo = std::min(std::max(lo - c0, 0), 4), nhi = std::min(std::max(c0 + 3 - hi, 0), 4);
+        const uint32_t mlo = nlo >= 4 ? 0u : (0xFFFFFFFFu << (8 * nlo));
+        const uint32_t mhi = nhi >= 4 ? 0u : (0xFFFFFFFFu >> (8 * nhi));
+        const uint32_t msk = mlo & mhi;
+        // byte j holds u + 32 = (c0 + j - 21) + 32 = c0 + j + 11  (15..50: no carry between bytes)
+        const uint32_t wfull = (uint32_t)(c0 + 11) * 0x01010101u + 0x03020100u;
+        mt[t] = make_uint4(wfull & msk, 0x01010101u & msk, (uint32_t)((6 + vr) * DW_RAW_STRIDE_H + c0), (uint32_t)v);
+    }
+    if (hipMemcpyToSymbol(HIP_SYMBOL(c_mom_tab), mt, sizeof(mt)) != hipSuccess) return -1;
+    static float4 pf[256];
+    for (int b = 0; b < 256; b++)
+        pf[b] = make_float4((float)ORBX_PATTERN[4 * b], (float)ORBX_PATTERN[4 * b + 1], (float)ORBX_PATTERN[4 * b + 2], (float)ORBX_PATTERN[4 * b + 3]);
+    if (hipMemcpyToSymbol(HIP_SYMBOL(c_pat_f), pf, sizeof(pf)) != hipSuccess) return -1;
     return 0;
 }
 
@@ -186,8 +214,9 @@ __global__ __launch_bounds__(256) void k_describe(
     const uint8_t *img = L.base + (long long)f * L.frame_stride;
 
     // this lane's four sample pairs (bits lane, lane+64, lane+128, lane+192); issued early
-    const uint32_t *pat32 = reinterpret_cast<const uint32_t *>(c_pattern);
-    const uint32_t pw0 = pat32[lane], pw1 = pat32[64 + lane], pw2 = pat32[128 + lane], pw3 = pat32[192 + lane];
+    uint4 mom[5];
+#pragma unroll
+    for (int it = 0; it < 5; it++) mom[it] = c_mom_tab[it * 64 + lane];
 
     // ---- raw tile -> LDS ----
     const int x0 = x - 21, y0 = y - 21;
@@ -228,28 +257,15 @@ __global__ __launch_bounds__(256) void k_describe(
     // dword tasks (row 0..30, dword 1..9 of the raw row); weights (u+32) keep the dot product unsigned
     int m10 = 0, m01 = 0;
     {
-        const unsigned long long unib = c_umax_nib;
+        static_assert(DW_RAW_STRIDE == DW_RAW_STRIDE_H, "c_mom_tab offsets");
 #pragma unroll
         for (int it = 0; it < 5; it++) {
-            const int t = it * 64 + lane;
-            if (t < 31 * 9) {
-                const int vr = t / 9, dw = t - vr * 9 + 1;
-                const int v = vr - 15;
-                const int um = (int)((unib >> (4 * abs(v))) & 15ull);
-                const int lo = 21 - um, hi = 21 + um;               // valid raw columns
-                const int c0 = 4 * dw;
-                const int nlo = min(max(lo - c0, 0), 4), nhi = min(max(c0 + 3 - hi, 0), 4);
-                const uint32_t mlo = nlo >= 4 ? 0u : (0xFFFFFFFFu << (8 * nlo));
-                const uint32_t mhi = nhi >= 4 ? 0u : (0xFFFFFFFFu >> (8 * nhi));
-                const uint32_t msk = mlo & mhi;
-                // byte j holds u + 32 = (c0 + j - 21) + 32 = c0 + j + 11  (15..50: no carry between bytes)
-                const uint32_t wfull = __builtin_amdgcn_perm(0u, (uint32_t)(c0 + 11), 0x00000000u) + 0x03020100u;   // byte broadcast (v_perm), not a 32-bit multiply
-                const uint32_t pix = *reinterpret_cast<const uint32_t *>(&S.raw[(6 + vr) * DW_RAW_STRIDE + c0]);
-                const int sA = (int)__builtin_amdgcn_udot4(pix, wfull & msk, 0u, false);
-                const int sB = (int)__builtin_amdgcn_udot4(pix, 0x01010101u & msk, 0u, false);
-                m10 += sA - 32 * sB;
-                m01 += __mul24(v, sB);
-            }
+            const uint4 e = mom[it];   // zero past the last task
+            const uint32_t pix = *reinterpret_cast<const uint32_t *>(&S.raw[e.z]);
+            const int sA = (int)__builtin_amdgcn_udot4(pix, e.x, 0u, false);
+            const int sB = (int)__builtin_amdgcn_udot4(pix, e.y, 0u, false);
+            m10 += sA - 32 * sB;
+            m01 += __mul24((int)e.w, sB);
         }
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) {
@@ -294,45 +310,40 @@ __global__ __launch_bounds__(256) void k_describe(
         const uint32_t K01 = k0 | (k1 << 16), K23 = k2 | (k3 << 16), K45 = k2 | (k1 << 16), K6_ = k0;       // even rows
         const uint32_t K_0 = k0 << 16, K12 = k1 | (k2 << 16), K34 = k3 | (k2 << 16), K56 = k1 | (k0 << 16); // odd rows
         const int simd_cols = plan.blur_mode == 1 ? (L.w & ~3) : 0;
-        if (lane < 57) {
-            const int blk = lane / 19, cp = lane - blk * 19;          // 3 blocks x 19 column pairs
-            const int q0 = blk == 0 ? 0 : blk == 1 ? 7 : 13;           // row-pair blocks [0,7) [7,13) [13,19)
-            const int nq = blk == 0 ? 7 : 6;
-            const int c = 2 * cp;
-            typedef unsigned short us2 __attribute__((ext_vector_type(2)));
-            uint2 w[4];
+        // task = (row pair q, column pair cp): 19 x 19 of them, each a 2 x 2 block of outputs from four 8-byte reads
 #pragma unroll
-            for (int j = 0; j < 3; j++) w[j + 1] = *reinterpret_cast<const uint2 *>(&S.P[(q0 + j) * DW_P_STRIDE + c]);
+        for (int it = 0; it < 6; it++) {
+            const int t = it * 64 + lane;
+            if (t < 19 * 19) {
+                const int q = (int)(__umul24((uint32_t)t, 3450u) >> 16);   // t / 19 for t < 384
+                const int c = 2 * (t - 19 * q);
+                typedef unsigned short us2 __attribute__((ext_vector_type(2)));
+                uint2 w[4];
 #pragma unroll
-            for (int qi = 0; qi < 7; qi++) {
-                if (qi < nq) {
-                    const int q = q0 + qi;
-                    w[0] = w[1]; w[1] = w[2]; w[2] = w[3];
-                    w[3] = *reinterpret_cast<const uint2 *>(&S.P[(q + 3) * DW_P_STRIDE + c]);
+                for (int j = 0; j < 4; j++) w[j] = *reinterpret_cast<const uint2 *>(&S.P[(q + j) * DW_P_STRIDE + c]);
 #define D2(A, K, ACC) __builtin_amdgcn_udot2(__builtin_bit_cast(us2, (A)), __builtin_bit_cast(us2, (uint32_t)(K)), (ACC), false)
-                    const uint32_t e0 = D2(w[0].x, K01, D2(w[1].x, K23, D2(w[2].x, K45, D2(w[3].x, K6_, 0u))));
-                    const uint32_t e1 = D2(w[0].y, K01, D2(w[1].y, K23, D2(w[2].y, K45, D2(w[3].y, K6_, 0u))));
-                    const uint32_t o0 = D2(w[0].x, K_0, D2(w[1].x, K12, D2(w[2].x, K34, D2(w[3].x, K56, 0u))));
-                    const uint32_t o1 = D2(w[0].y, K_0, D2(w[1].y, K12, D2(w[2].y, K34, D2(w[3].y, K56, 0u))));
+                const uint32_t e0 = D2(w[0].x, K01, D2(w[1].x, K23, D2(w[2].x, K45, D2(w[3].x, K6_, 0u))));
+                const uint32_t e1 = D2(w[0].y, K01, D2(w[1].y, K23, D2(w[2].y, K45, D2(w[3].y, K6_, 0u))));
+                const uint32_t o0 = D2(w[0].x, K_0, D2(w[1].x, K12, D2(w[2].x, K34, D2(w[3].x, K56, 0u))));
+                const uint32_t o1 = D2(w[0].y, K_0, D2(w[1].y, K12, D2(w[2].y, K34, D2(w[3].y, K56, 0u))));
 #undef D2
-                    const uint32_t s4[4] = {e0, e1, o0, o1};
-                    uint32_t v4[4];
-                    if (simd_cols == 0) {   // wave-uniform: OpenCV portable C path, (sum + 32768) >> 16 saturated
+                const uint32_t s4[4] = {e0, e1, o0, o1};
+                uint32_t v4[4];
+                if (simd_cols == 0) {   // wave-uniform: OpenCV portable C path, (sum + 32768) >> 16 saturated
 #pragma unroll
-                        for (int z = 0; z < 4; z++) v4[z] = min((s4[z] + 32768u) >> 16, 255u);
-                    } else {                // x86 SSE2 path for columns < simd_cols: an exact .5 tie rounds to even
+                    for (int z = 0; z < 4; z++) v4[z] = min((s4[z] + 32768u) >> 16, 255u);
+                } else {                // x86 SSE2 path for columns < simd_cols: an exact .5 tie rounds to even
 #pragma unroll
-                        for (int z = 0; z < 4; z++) {
-                            uint32_t v = (s4[z] + 32768u) >> 16;
-                            const bool tie_to_even = (x - DESC_R + c + (z & 1) < simd_cols) && ((s4[z] & 0xFFFFu) == 0x8000u) && (v & 1u);
-                            v -= tie_to_even ? 1u : 0u;
-                            v4[z] = min(v, 255u);
-                        }
+                    for (int z = 0; z < 4; z++) {
+                        uint32_t v = (s4[z] + 32768u) >> 16;
+                        const bool tie_to_even = (x - DESC_R + c + (z & 1) < simd_cols) && ((s4[z] & 0xFFFFu) == 0x8000u) && (v & 1u);
+                        v -= tie_to_even ? 1u : 0u;
+                        v4[z] = min(v, 255u);
                     }
-                    *reinterpret_cast<uint16_t *>(&bl[(2 * q) * DW_BL_STRIDE + c]) = (uint16_t)(v4[0] | (v4[1] << 8));
-                    if (2 * q + 1 < DESC_BL)
-                        *reinterpret_cast<uint16_t *>(&bl[(2 * q + 1) * DW_BL_STRIDE + c]) = (uint16_t)(v4[2] | (v4[3] << 8));
                 }
+                *reinterpret_cast<uint16_t *>(&bl[(2 * q) * DW_BL_STRIDE + c]) = (uint16_t)(v4[0] | (v4[1] << 8));
+                if (2 * q + 1 < DESC_BL)
+                    *reinterpret_cast<uint16_t *>(&bl[(2 * q + 1) * DW_BL_STRIDE + c]) = (uint16_t)(v4[2] | (v4[3] << 8));
             }
         }
     }
@@ -344,12 +355,12 @@ __global__ __launch_bounds__(256) void k_describe(
     float a, b;
     sincos_cr(__fmul_rn(angle, factorPI), &a, &b);
     unsigned long long bits[4];
-    const uint32_t pws[4] = {pw0, pw1, pw2, pw3};
+    float4 pf[4];
+#pragma unroll
+    for (int j = 0; j < 4; j++) pf[j] = c_pat_f[j * 64 + lane];   // bits lane, lane + 64, lane + 128, lane + 192
 #pragma unroll
     for (int j = 0; j < 4; j++) {
-        const uint32_t pw = pws[j];
-        const float px0 = (float)(int)(signed char)(pw & 0xFF), py0 = (float)(int)(signed char)((pw >> 8) & 0xFF);
-        const float px1 = (float)(int)(signed char)((pw >> 16) & 0xFF), py1 = (float)(int)(signed char)(pw >> 24);
+        const float px0 = pf[j].x, py0 = pf[j].y, px1 = pf[j].z, py1 = pf[j].w;
         const int r0 = __float2int_rn(__fadd_rn(__fmul_rn(px0, b), __fmul_rn(py0, a)));
         const int q0 = __float2int_rn(__fsub_rn(__fmul_rn(px0, a), __fmul_rn(py0, b)));
         const int r1 = __float2int_rn(__fadd_rn(__fmul_rn(px1, b), __fmul_rn(py1, a)));
