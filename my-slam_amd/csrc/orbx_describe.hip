@@ -5,7 +5,9 @@
 #include "orbx_internal.h"
 #include "orb_pattern_data.h"
 #include <algorithm>
+#include <math.h>
 #define DW_RAW_STRIDE_H 48   // = DW_RAW_STRIDE below (host-side table builder)
+#define DESC_R_H 18          // = DESC_R
 
 __constant__ unsigned long long c_umax_nib;   // umax[v] in nibble v (v = 0..15)
 __constant__ int c_gauss[7];
@@ -14,6 +16,13 @@ __constant__ signed char c_pattern[1024];
 //   x = weights (u + 32 per byte, 0 outside the disc), y = 1 per byte inside the disc, z = byte offset of the dword in
 //   the raw tile, w = v (row offset, -15..15).  Replaces ~20 instructions of mask arithmetic per task.
 __constant__ uint4 c_mom_tab[320];
+// Blur task lists.  Only blurred pixels a rotated sample can land on are produced: |rotated p| <= |p|max and each
+// coordinate is rounded, so integer (r, q) with r*r + q*q <= (|p|max + 0.72)^2 (1125 of the 37 x 37 = 1369 positions;
+// |p|max = 18.38 for the ORB pattern).  Row task = (row pair, 4-column group) -> 189 of 220; column task = 2 x 2 output
+// block -> 300 of 361.  Entries: row: raw byte offset | P dword offset << 16; column: P dword offset | bl byte offset
+// << 10 | first column << 21 | (second row exists) << 27.  0xFFFFFFFF = no task.
+__constant__ uint32_t c_row_task[192];
+__constant__ uint32_t c_col_task[320];
 // rBRIEF sample pairs as floats: (x0, y0, x1, y1) of bit b -- the int8 -> float conversions done once on the host
 __constant__ float4 c_pat_f[256];
 
@@ -43,6 +52,36 @@ int orbx_upload_constants(const int umax[16], const int gauss_k[7])
         mt[t] = make_uint4(wfull & msk, 0x01010101u & msk, (uint32_t)((6 + vr) * DW_RAW_STRIDE_H + c0), (uint32_t)v);
     }
     if (hipMemcpyToSymbol(HIP_SYMBOL(c_mom_tab), mt, sizeof(mt)) != hipSuccess) return -1;
+    {
+        int maxr2 = 0;
+        for (int i = 0; i < 512; i++) maxr2 = std::max(maxr2, (int)ORBX_PATTERN[2 * i] * ORBX_PATTERN[2 * i] + (int)ORBX_PATTERN[2 * i + 1] * ORBX_PATTERN[2 * i + 1]);
+        const double R = sqrt((double)maxr2) + 0.72;
+        if (R > DESC_R_H + 1.5) return -1;   // the 37 x 37 tile would not hold the pattern
+        bool need[37][37];
+        for (int i = 0; i < 37; i++)
+            for (int j = 0; j < 37; j++) need[i][j] = (double)((i - 18) * (i - 18) + (j - 18) * (j - 18)) <= R * R;
+        static uint32_t rt[192], ct[320];
+        int nr = 0, nc = 0;
+        for (int rp = 0; rp < 22; rp++)
+            for (int gq = 0; gq < 10; gq++) {
+                bool ok = false;
+                for (int row = 2 * rp; row <= 2 * rp + 1; row++)
+                    for (int col = 4 * gq; col < 4 * gq + 4 && col < 37; col++)
+                        for (int i = std::max(row - 6, 0); i <= std::min(row, 36); i++) ok = ok || need[i][col];
+                if (ok) { if (nr >= 192) return -1; rt[nr++] = (uint32_t)((2 * rp) * DW_RAW_STRIDE_H + 4 * gq) | ((uint32_t)(rp * 40 + 4 * gq) << 16); }
+            }
+        for (int q = 0; q < 19; q++)
+            for (int cp = 0; cp < 19; cp++) {
+                bool ok = false;
+                for (int i = 2 * q; i <= 2 * q + 1 && i < 37; i++)
+                    for (int j = 2 * cp; j <= 2 * cp + 1 && j < 37; j++) ok = ok || need[i][j];
+                if (ok) { if (nc >= 320) return -1; ct[nc++] = (uint32_t)(q * 40 + 2 * cp) | ((uint32_t)(80 * q + 2 * cp) << 10) | ((uint32_t)(2 * cp) << 21) | ((2 * q + 1 < 37 ? 1u : 0u) << 27); }
+            }
+        for (; nr < 192; nr++) rt[nr] = 0xFFFFFFFFu;
+        for (; nc < 320; nc++) ct[nc] = 0xFFFFFFFFu;
+        if (hipMemcpyToSymbol(HIP_SYMBOL(c_row_task), rt, sizeof(rt)) != hipSuccess) return -1;
+        if (hipMemcpyToSymbol(HIP_SYMBOL(c_col_task), ct, sizeof(ct)) != hipSuccess) return -1;
+    }
     static float4 pf[256];
     for (int b = 0; b < 256; b++)
         pf[b] = make_float4((float)ORBX_PATTERN[4 * b], (float)ORBX_PATTERN[4 * b + 1], (float)ORBX_PATTERN[4 * b + 2], (float)ORBX_PATTERN[4 * b + 3]);
@@ -217,6 +256,11 @@ __global__ __launch_bounds__(256) void k_describe(
     uint4 mom[5];
 #pragma unroll
     for (int it = 0; it < 5; it++) mom[it] = c_mom_tab[it * 64 + lane];
+    uint32_t rtask[3], ctask[5];
+#pragma unroll
+    for (int it = 0; it < 3; it++) rtask[it] = c_row_task[it * 64 + lane];
+#pragma unroll
+    for (int it = 0; it < 5; it++) ctask[it] = c_col_task[it * 64 + lane];
 
     // ---- raw tile -> LDS ----
     const int x0 = x - 21, y0 = y - 21;
@@ -280,13 +324,13 @@ __global__ __launch_bounds__(256) void k_describe(
     const uint32_t k0 = (uint32_t)c_gauss[0], k1 = (uint32_t)c_gauss[1], k2 = (uint32_t)c_gauss[2], k3 = (uint32_t)c_gauss[3];
     const uint32_t KA = k0 | (k1 << 8) | (k2 << 16) | (k3 << 24);     // taps 0..3
     const uint32_t KB = k2 | (k1 << 8) | (k0 << 16);                  // taps 4..6 (symmetric kernel), tap 7 = 0
+    static_assert(DW_P_STRIDE == 40 && DW_BL_STRIDE == 40 && DESC_R == DESC_R_H, "task tables");
 #pragma unroll
-    for (int it = 0; it < 4; it++) {
-        const int t = it * 64 + lane;
-        if (t < DW_P_ROWS * 10) {
-            const int rp = t / 10, gq = t - rp * 10;
-            const uint32_t *ra = reinterpret_cast<const uint32_t *>(&S.raw[(2 * rp) * DW_RAW_STRIDE + 4 * gq]);
-            const uint32_t *rbp = reinterpret_cast<const uint32_t *>(&S.raw[(2 * rp + 1) * DW_RAW_STRIDE + 4 * gq]);
+    for (int it = 0; it < 3; it++) {
+        const uint32_t te = rtask[it];
+        if (te != 0xFFFFFFFFu) {
+            const uint32_t *ra = reinterpret_cast<const uint32_t *>(&S.raw[te & 0xFFFFu]);
+            const uint32_t *rbp = reinterpret_cast<const uint32_t *>(&S.raw[(te & 0xFFFFu) + DW_RAW_STRIDE]);
             const uint32_t a0 = ra[0], a1 = ra[1], a2 = ra[2];
             const uint32_t b0 = rbp[0], b1 = rbp[1], b2 = rbp[2];
             uint32_t o[4];
@@ -298,7 +342,7 @@ __global__ __launch_bounds__(256) void k_describe(
             o[2] = ROWOUT(2, a0, a1, a2) | (ROWOUT(2, b0, b1, b2) << 16);
             o[3] = ROWOUT(3, a0, a1, a2) | (ROWOUT(3, b0, b1, b2) << 16);
 #undef ROWOUT
-            *reinterpret_cast<uint4 *>(&S.P[rp * DW_P_STRIDE + 4 * gq]) = make_uint4(o[0], o[1], o[2], o[3]);
+            *reinterpret_cast<uint4 *>(&S.P[te >> 16]) = make_uint4(o[0], o[1], o[2], o[3]);
         }
     }
     DSYNC();
@@ -310,17 +354,18 @@ __global__ __launch_bounds__(256) void k_describe(
         const uint32_t K01 = k0 | (k1 << 16), K23 = k2 | (k3 << 16), K45 = k2 | (k1 << 16), K6_ = k0;       // even rows
         const uint32_t K_0 = k0 << 16, K12 = k1 | (k2 << 16), K34 = k3 | (k2 << 16), K56 = k1 | (k0 << 16); // odd rows
         const int simd_cols = plan.blur_mode == 1 ? (L.w & ~3) : 0;
-        // task = (row pair q, column pair cp): 19 x 19 of them, each a 2 x 2 block of outputs from four 8-byte reads
+        // task = 2 x 2 block of outputs from four 8-byte reads (c_col_task)
 #pragma unroll
-        for (int it = 0; it < 6; it++) {
-            const int t = it * 64 + lane;
-            if (t < 19 * 19) {
-                const int q = (int)(__umul24((uint32_t)t, 3450u) >> 16);   // t / 19 for t < 384
-                const int c = 2 * (t - 19 * q);
+        for (int it = 0; it < 5; it++) {
+            const uint32_t te = ctask[it];
+            if (te != 0xFFFFFFFFu) {
+                const int c = (int)((te >> 21) & 63u);
+                const uint32_t *pin = &S.P[te & 1023u];
+                uint8_t *pout = &bl[(te >> 10) & 2047u];
                 typedef unsigned short us2 __attribute__((ext_vector_type(2)));
                 uint2 w[4];
 #pragma unroll
-                for (int j = 0; j < 4; j++) w[j] = *reinterpret_cast<const uint2 *>(&S.P[(q + j) * DW_P_STRIDE + c]);
+                for (int j = 0; j < 4; j++) w[j] = *reinterpret_cast<const uint2 *>(pin + j * DW_P_STRIDE);
 #define D2(A, K, ACC) __builtin_amdgcn_udot2(__builtin_bit_cast(us2, (A)), __builtin_bit_cast(us2, (uint32_t)(K)), (ACC), false)
                 const uint32_t e0 = D2(w[0].x, K01, D2(w[1].x, K23, D2(w[2].x, K45, D2(w[3].x, K6_, 0u))));
                 const uint32_t e1 = D2(w[0].y, K01, D2(w[1].y, K23, D2(w[2].y, K45, D2(w[3].y, K6_, 0u))));
@@ -341,9 +386,9 @@ __global__ __launch_bounds__(256) void k_describe(
                         v4[z] = min(v, 255u);
                     }
                 }
-                *reinterpret_cast<uint16_t *>(&bl[(2 * q) * DW_BL_STRIDE + c]) = (uint16_t)(v4[0] | (v4[1] << 8));
-                if (2 * q + 1 < DESC_BL)
-                    *reinterpret_cast<uint16_t *>(&bl[(2 * q + 1) * DW_BL_STRIDE + c]) = (uint16_t)(v4[2] | (v4[3] << 8));
+                *reinterpret_cast<uint16_t *>(pout) = (uint16_t)(v4[0] | (v4[1] << 8));
+                if (te & (1u << 27))
+                    *reinterpret_cast<uint16_t *>(pout + DW_BL_STRIDE) = (uint16_t)(v4[2] | (v4[3] << 8));
             }
         }
     }
