@@ -12,10 +12,10 @@
 __constant__ unsigned long long c_umax_nib;   // umax[v] in nibble v (v = 0..15)
 __constant__ int c_gauss[7];
 __constant__ signed char c_pattern[1024];
-// Per-task constants of the IC_Angle dword tasks (t = row * 9 + dword - 1, 31 rows x 9 dwords, padded to 320):
+// Per-task constants of the IC_Angle dword tasks (31 rows x dwords 1..9 of the raw row that touch the disc: 213, padded to 256):
 //   x = weights (u + 32 per byte, 0 outside the disc), y = 1 per byte inside the disc, z = byte offset of the dword in
 //   the raw tile, w = v (row offset, -15..15).  Replaces ~20 instructions of mask arithmetic per task.
-__constant__ uint4 c_mom_tab[320];
+__constant__ uint4 c_mom_tab[256];
 // Blur task lists.  Only blurred pixels a rotated sample can land on are produced: |rotated p| <= |p|max and each
 // coordinate is rounded, so integer (r, q) with r*r + q*q <= (|p|max + 0.72)^2 (1125 of the 37 x 37 = 1369 positions;
 // |p|max = 18.38 for the ORB pattern).  Row task = (row pair, 4-column group) -> 189 of 220; column task = 2 x 2 output
@@ -23,7 +23,7 @@ __constant__ uint4 c_mom_tab[320];
 // << 10 | first column << 21 | (second row exists) << 27.  0xFFFFFFFF = no task.
 __constant__ uint32_t c_row_task[192];
 __constant__ uint32_t c_col_task[320];
-// rBRIEF sample pairs as floats: (x0, y0, x1, y1) of bit b -- the int8 -> float conversions done once on the host
+// rBRIEF sample pairs as floats: (x0, x1, y0, y1) of bit b -- the int8 -> float conversions done once on the host
 __constant__ float4 c_pat_f[256];
 
 int orbx_upload_constants(const int umax[16], const int gauss_k[7])
@@ -36,10 +36,10 @@ int orbx_upload_constants(const int umax[16], const int gauss_k[7])
     if (hipMemcpyToSymbol(HIP_SYMBOL(c_umax_nib), &nib, sizeof(nib)) != hipSuccess) return -1;
     if (hipMemcpyToSymbol(HIP_SYMBOL(c_gauss), gauss_k, sizeof(int) * 7) != hipSuccess) return -1;
     if (hipMemcpyToSymbol(HIP_SYMBOL(c_pattern), ORBX_PATTERN, 1024) != hipSuccess) return -1;
-    static uint4 mt[320];
-    for (int t = 0; t < 320; t++) {
-        mt[t] = make_uint4(0u, 0u, 0u, 0u);
-        if (t >= 31 * 9) continue;
+    static uint4 mt[256];
+    int nmt = 0;
+    for (int t = 0; t < 256; t++) mt[t] = make_uint4(0u, 0u, 0u, 0u);
+    for (int t = 0; t < 31 * 9; t++) {
         const int vr = t / 9, dw = t - vr * 9 + 1, v = vr - 15;
         const int um = umax[v < 0 ? -v : v];
         const int lo = 21 - um, hi = 21 + um, c0 = 4 * dw;                  // valid raw columns; first column of this dword
@@ -49,7 +49,9 @@ int orbx_upload_constants(const int umax[16], const int gauss_k[7])
         const uint32_t msk = mlo & mhi;
         // byte j holds u + 32 = (c0 + j - 21) + 32 = c0 + j + 11  (15..50: no carry between bytes)
         const uint32_t wfull = (uint32_t)(c0 + 11) * 0x01010101u + 0x03020100u;
-        mt[t] = make_uint4(wfull & msk, 0x01010101u & msk, (uint32_t)((6 + vr) * DW_RAW_STRIDE_H + c0), (uint32_t)v);
+        if (msk == 0) continue;          // dword entirely outside the disc: 213 tasks remain (4 wave passes)
+        if (nmt >= 256) return -1;
+        mt[nmt++] = make_uint4(wfull & msk, 0x01010101u & msk, (uint32_t)((6 + vr) * DW_RAW_STRIDE_H + c0), (uint32_t)v);
     }
     if (hipMemcpyToSymbol(HIP_SYMBOL(c_mom_tab), mt, sizeof(mt)) != hipSuccess) return -1;
     {
@@ -84,7 +86,7 @@ int orbx_upload_constants(const int umax[16], const int gauss_k[7])
     }
     static float4 pf[256];
     for (int b = 0; b < 256; b++)
-        pf[b] = make_float4((float)ORBX_PATTERN[4 * b], (float)ORBX_PATTERN[4 * b + 1], (float)ORBX_PATTERN[4 * b + 2], (float)ORBX_PATTERN[4 * b + 3]);
+        pf[b] = make_float4((float)ORBX_PATTERN[4 * b], (float)ORBX_PATTERN[4 * b + 2], (float)ORBX_PATTERN[4 * b + 1], (float)ORBX_PATTERN[4 * b + 3]);
     if (hipMemcpyToSymbol(HIP_SYMBOL(c_pat_f), pf, sizeof(pf)) != hipSuccess) return -1;
     return 0;
 }
@@ -253,9 +255,9 @@ __global__ __launch_bounds__(256) void k_describe(
     const uint8_t *img = L.base + (long long)f * L.frame_stride;
 
     // this lane's four sample pairs (bits lane, lane+64, lane+128, lane+192); issued early
-    uint4 mom[5];
+    uint4 mom[4];
 #pragma unroll
-    for (int it = 0; it < 5; it++) mom[it] = c_mom_tab[it * 64 + lane];
+    for (int it = 0; it < 4; it++) mom[it] = c_mom_tab[it * 64 + lane];
     uint32_t rtask[3], ctask[5];
 #pragma unroll
     for (int it = 0; it < 3; it++) rtask[it] = c_row_task[it * 64 + lane];
@@ -303,7 +305,7 @@ __global__ __launch_bounds__(256) void k_describe(
     {
         static_assert(DW_RAW_STRIDE == DW_RAW_STRIDE_H, "c_mom_tab offsets");
 #pragma unroll
-        for (int it = 0; it < 5; it++) {
+        for (int it = 0; it < 4; it++) {
             const uint4 e = mom[it];   // zero past the last task
             const uint32_t pix = *reinterpret_cast<const uint32_t *>(&S.raw[e.z]);
             const int sA = (int)__builtin_amdgcn_udot4(pix, e.x, 0u, false);
@@ -403,15 +405,23 @@ __global__ __launch_bounds__(256) void k_describe(
     float4 pf[4];
 #pragma unroll
     for (int j = 0; j < 4; j++) pf[j] = c_pat_f[j * 64 + lane];   // bits lane, lane + 64, lane + 128, lane + 192
+    // Both samples of a pair in one packed-fp32 lane pair (v_pk_mul_f32 / v_pk_add_f32: the same IEEE operations, two per
+    // instruction; no FMA is formed, the file is built with -ffp-contract=off).  cvRound = round-half-even = adding
+    // 1.5 * 2^23: the integer then sits in the low mantissa bits (|value| <= 19), so index = mad24(ri, 40, qi) - const
+    // (unsigned wrap-around arithmetic on the index, never on the pointer).
+    typedef float f2 __attribute__((ext_vector_type(2)));
+    const f2 A = {a, a}, Bv = {b, b}, MAGIC = {12582912.f, 12582912.f};
+    // bits(MAGIC + r) = 0x4B400000 + r; mad24 sees its low 24 bits, 0x400000 + r
+    const uint32_t IDX_BIAS = 0x400000u * (uint32_t)DW_BL_STRIDE + 0x4B400000u - (uint32_t)(DESC_R * DW_BL_STRIDE + DESC_R);
 #pragma unroll
     for (int j = 0; j < 4; j++) {
-        const float px0 = pf[j].x, py0 = pf[j].y, px1 = pf[j].z, py1 = pf[j].w;
-        const int r0 = __float2int_rn(__fadd_rn(__fmul_rn(px0, b), __fmul_rn(py0, a)));
-        const int q0 = __float2int_rn(__fsub_rn(__fmul_rn(px0, a), __fmul_rn(py0, b)));
-        const int r1 = __float2int_rn(__fadd_rn(__fmul_rn(px1, b), __fmul_rn(py1, a)));
-        const int q1 = __float2int_rn(__fsub_rn(__fmul_rn(px1, a), __fmul_rn(py1, b)));
-        const int t0 = bl[__mul24(DESC_R + r0, DW_BL_STRIDE) + DESC_R + q0];
-        const int t1 = bl[__mul24(DESC_R + r1, DW_BL_STRIDE) + DESC_R + q1];
+        const f2 PX = {pf[j].x, pf[j].y}, PY = {pf[j].z, pf[j].w};      // (x0, x1), (y0, y1)
+        const f2 R = (PX * Bv + PY * A) + MAGIC;                          // rows:    x * sin + y * cos
+        const f2 Q = (PX * A - PY * Bv) + MAGIC;                          // columns: x * cos - y * sin
+        const uint32_t i0 = __umul24(__float_as_uint(R.x), (uint32_t)DW_BL_STRIDE) + __float_as_uint(Q.x) - IDX_BIAS;
+        const uint32_t i1 = __umul24(__float_as_uint(R.y), (uint32_t)DW_BL_STRIDE) + __float_as_uint(Q.y) - IDX_BIAS;
+        const int t0 = bl[i0];
+        const int t1 = bl[i1];
         bits[j] = __builtin_amdgcn_ballot_w64(t0 < t1);
     }
     const long long o = (long long)f * plan.out_cap + g;
