@@ -359,7 +359,9 @@ static int check_csr(const int32_t *off, const int32_t *idx, int nq, int nt, int
 static int pick_splits(int nq_cap, int nbatch, int nt_hint)
 {
     const long long waves = (long long)nbatch * ((nq_cap + M_THREADS - 1) / M_THREADS) * (M_THREADS / 64);
-    int S = (int)((4096 + waves - 1) / waves);
+    // ~12 waves per SIMD over the launch (measured on MI355X: 2048..16384 waves -> 76, 69, 64, 62, 57, 58 us for 63 x 1007^2
+    // pairs): more, shorter waves hide the LDS broadcast latency and even out the tail
+    int S = (int)((12288 + waves - 1) / waves);
     S = std::max(1, std::min(S, 64));
     while (S > 1 && nt_hint / S < 16) S--;       // keep >= 16 train descriptors per split
     return S;

@@ -100,7 +100,7 @@ __global__ __launch_bounds__(256) void k_resize_linear_4x4(
             const uint8_t *p = S + (__mul24(rr ? sy1 : sy0, sstride) + base);   // offsets inside a frame fit 31 bits; 24-bit multiply is full rate
             sh8[r][rr] = (uint32_t)((uintptr_t)p & 3u);
             const uint32_t *q = reinterpret_cast<const uint32_t *>(p - sh8[r][rr]);
-            if (CHECK) {
+            if (CHECK && blockIdx.z == gridDim.z - 1) {   // only the last frame can end at the end of the caller's buffer
                 wv[r][rr][0] = q[0];
                 wv[r][rr][1] = (reinterpret_cast<const uint8_t *>(q + 2) <= src_end) ? q[1] : 0u;
                 wv[r][rr][2] = (reinterpret_cast<const uint8_t *>(q + 3) <= src_end) ? q[2] : 0u;
