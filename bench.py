@@ -88,6 +88,13 @@ def cpu_baseline(frames, nfeatures, budget_s=12.0, all_cores_s=8.0):
         ncore = len(os.sched_getaffinity(0))
     except Exception:
         ncore = os.cpu_count() or 1
+    try:   # a container's CPU quota (cgroup v2 cpu.max = "<quota> <period>") is the real core count
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            ncore = max(1, min(ncore, int(round(int(quota) / int(period)))))
+    except Exception:
+        pass
+    ncore = min(ncore, 64)
     if ncore > 1 and all_cores_s > 0:
         import threading
         tot = [0, 0]
