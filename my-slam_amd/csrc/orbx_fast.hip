@@ -72,9 +72,18 @@ __device__ __forceinline__ uint32_t reject4(us2 c, us2 t, us2 a0, us2 a8, us2 a4
     return as_u32(dark) | as_u32(bright);
 }
 
-// stage 2 for up to 128 queued survivors, TWO pixels per lane in the two i16 halves of every register:
+// stage 2 for up to 128 queued survivors, TWO pixels per lane in the two fp16 halves of every register:
 // corner score = max over the 16 nine-arcs of min(d) / min(-d), minus 1 (d = centre - circle pixel).
 // A pixel is a corner at threshold t  <=>  score >= t, so no separate arc test is needed.
+// The values are small integers (|d| <= 255), exact in fp16, and gfx950 has three-input packed fp16 min/max
+// (v_pk_minimum3_f16 / v_pk_maximum3_f16): a 9-window is min3 of three min3's, so one polarity costs
+// 16 + 16 + 8 instructions instead of the 79 of a two-input tree.  A byte b becomes the fp16 number 1024 + b by
+// OR-ing 0x6400 into its half (ulp is 1 in [1024, 2048)); the bias cancels in d.
+typedef _Float16 hh2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ hh2 pkh(uint32_t lo, uint32_t hi) { return __builtin_bit_cast(hh2, (lo | (hi << 16)) | 0x64006400u); }
+__device__ __forceinline__ hh2 hmin3(hh2 a, hh2 b, hh2 c) { return __builtin_elementwise_minimum(__builtin_elementwise_minimum(a, b), c); }
+__device__ __forceinline__ hh2 hmax3(hh2 a, hh2 b, hh2 c) { return __builtin_elementwise_maximum(__builtin_elementwise_maximum(a, b), c); }
+
 template <int TS, int ZS>
 __device__ __forceinline__ void fast_stage2(const uint8_t *T0, const uint16_t *queue, uint8_t *smap, int cnt,
                                             int lane, int t_lo, bool *c0, bool *c1, int *pos0, int *pos1)
@@ -86,39 +95,39 @@ __device__ __forceinline__ void fast_stage2(const uint8_t *T0, const uint16_t *q
     *pos0 = pa; *pos1 = pb;
     const uint8_t *p = T0 + __umul24((uint32_t)(pa >> 6) + 3u, (uint32_t)TS) + (pa & 63) + 3;
     const uint8_t *q = T0 + __umul24((uint32_t)(pb >> 6) + 3u, (uint32_t)TS) + (pb & 63) + 3;
-    const ss2 v = pk(p[0], q[0]);
-    ss2 d[16];
-    d[0] = v - pk(p[3 * TS], q[3 * TS]);            d[1] = v - pk(p[3 * TS + 1], q[3 * TS + 1]);
-    d[2] = v - pk(p[2 * TS + 2], q[2 * TS + 2]);    d[3] = v - pk(p[1 * TS + 3], q[1 * TS + 3]);
-    d[4] = v - pk(p[3], q[3]);                      d[5] = v - pk(p[-1 * TS + 3], q[-1 * TS + 3]);
-    d[6] = v - pk(p[-2 * TS + 2], q[-2 * TS + 2]);  d[7] = v - pk(p[-3 * TS + 1], q[-3 * TS + 1]);
-    d[8] = v - pk(p[-3 * TS], q[-3 * TS]);          d[9] = v - pk(p[-3 * TS - 1], q[-3 * TS - 1]);
-    d[10] = v - pk(p[-2 * TS - 2], q[-2 * TS - 2]); d[11] = v - pk(p[-1 * TS - 3], q[-1 * TS - 3]);
-    d[12] = v - pk(p[-3], q[-3]);                   d[13] = v - pk(p[1 * TS - 3], q[1 * TS - 3]);
-    d[14] = v - pk(p[2 * TS - 2], q[2 * TS - 2]);   d[15] = v - pk(p[3 * TS - 1], q[3 * TS - 1]);
-    ss2 A = pk(-256, -256), B = pk(256, 256);
-    {
-        ss2 a2[16], a4[16];
+    const hh2 v = pkh(p[0], q[0]);
+    hh2 d[16];
+    d[0] = v - pkh(p[3 * TS], q[3 * TS]);            d[1] = v - pkh(p[3 * TS + 1], q[3 * TS + 1]);
+    d[2] = v - pkh(p[2 * TS + 2], q[2 * TS + 2]);    d[3] = v - pkh(p[1 * TS + 3], q[1 * TS + 3]);
+    d[4] = v - pkh(p[3], q[3]);                      d[5] = v - pkh(p[-1 * TS + 3], q[-1 * TS + 3]);
+    d[6] = v - pkh(p[-2 * TS + 2], q[-2 * TS + 2]);  d[7] = v - pkh(p[-3 * TS + 1], q[-3 * TS + 1]);
+    d[8] = v - pkh(p[-3 * TS], q[-3 * TS]);          d[9] = v - pkh(p[-3 * TS - 1], q[-3 * TS - 1]);
+    d[10] = v - pkh(p[-2 * TS - 2], q[-2 * TS - 2]); d[11] = v - pkh(p[-1 * TS - 3], q[-1 * TS - 3]);
+    d[12] = v - pkh(p[-3], q[-3]);                   d[13] = v - pkh(p[1 * TS - 3], q[1 * TS - 3]);
+    d[14] = v - pkh(p[2 * TS - 2], q[2 * TS - 2]);   d[15] = v - pkh(p[3 * TS - 1], q[3 * TS - 1]);
+    hh2 A, B;
+    {   // A = max over the 16 arcs of the minimum of their 9 values
+        hh2 m3[16], m9[16];
 #pragma unroll
-        for (int k = 0; k < 16; k++) a2[k] = __builtin_elementwise_min(d[k], d[(k + 1) & 15]);
+        for (int k = 0; k < 16; k++) m3[k] = hmin3(d[k], d[(k + 1) & 15], d[(k + 2) & 15]);
 #pragma unroll
-        for (int k = 0; k < 16; k++) a4[k] = __builtin_elementwise_min(a2[k], a2[(k + 2) & 15]);
-#pragma unroll
-        for (int k = 0; k < 16; k++)
-            A = __builtin_elementwise_max(A, __builtin_elementwise_min(__builtin_elementwise_min(a4[k], a4[(k + 4) & 15]), d[(k + 8) & 15]));
+        for (int k = 0; k < 16; k++) m9[k] = hmin3(m3[k], m3[(k + 3) & 15], m3[(k + 6) & 15]);
+        const hh2 a0 = hmax3(m9[0], m9[1], m9[2]), a1 = hmax3(m9[3], m9[4], m9[5]), a2 = hmax3(m9[6], m9[7], m9[8]);
+        const hh2 a3 = hmax3(m9[9], m9[10], m9[11]), a4 = hmax3(m9[12], m9[13], m9[14]);
+        A = hmax3(hmax3(a0, a1, a2), hmax3(a3, a4, m9[15]), a0);
     }
-    {
-        ss2 b2[16], b4[16];
+    {   // B = min over the arcs of the maximum (the bright polarity, negated below)
+        hh2 m3[16], m9[16];
 #pragma unroll
-        for (int k = 0; k < 16; k++) b2[k] = __builtin_elementwise_max(d[k], d[(k + 1) & 15]);
+        for (int k = 0; k < 16; k++) m3[k] = hmax3(d[k], d[(k + 1) & 15], d[(k + 2) & 15]);
 #pragma unroll
-        for (int k = 0; k < 16; k++) b4[k] = __builtin_elementwise_max(b2[k], b2[(k + 2) & 15]);
-#pragma unroll
-        for (int k = 0; k < 16; k++)
-            B = __builtin_elementwise_min(B, __builtin_elementwise_max(__builtin_elementwise_max(b4[k], b4[(k + 4) & 15]), d[(k + 8) & 15]));
+        for (int k = 0; k < 16; k++) m9[k] = hmax3(m3[k], m3[(k + 3) & 15], m3[(k + 6) & 15]);
+        const hh2 b0 = hmin3(m9[0], m9[1], m9[2]), b1 = hmin3(m9[3], m9[4], m9[5]), b2 = hmin3(m9[6], m9[7], m9[8]);
+        const hh2 b3 = hmin3(m9[9], m9[10], m9[11]), b4 = hmin3(m9[12], m9[13], m9[14]);
+        B = hmin3(hmin3(b0, b1, b2), hmin3(b3, b4, m9[15]), b0);
     }
-    const ss2 sc = __builtin_elementwise_max(A, -B) - pk(1, 1);   // <= 254
-    const int s0 = sc.x, s1 = sc.y;
+    const hh2 sc = __builtin_elementwise_maximum(A, -B);   // score + 1, an integer in [-255, 255]
+    const int s0 = (int)(float)sc.x - 1, s1 = (int)(float)sc.y - 1;
     if (s0 >= t_lo) { smap[__umul24((uint32_t)(pa >> 6) + 1u, (uint32_t)ZS) + (pa & 63) + 1] = (uint8_t)s0; *c0 = true; }
     if (two && s1 >= t_lo) { smap[__umul24((uint32_t)(pb >> 6) + 1u, (uint32_t)ZS) + (pb & 63) + 1] = (uint8_t)s1; *c1 = true; }
 }
