@@ -77,10 +77,12 @@ __device__ __forceinline__ uint32_t reject4(us2 c, us2 t, us2 a0, us2 a8, us2 a4
 // A pixel is a corner at threshold t  <=>  score >= t, so no separate arc test is needed.
 // The values are small integers (|d| <= 255), exact in fp16, and gfx950 has three-input packed fp16 min/max
 // (v_pk_minimum3_f16 / v_pk_maximum3_f16): a 9-window is min3 of three min3's, so one polarity costs
-// 16 + 16 + 8 instructions instead of the 79 of a two-input tree.  A byte b becomes the fp16 number 1024 + b by
-// OR-ing 0x6400 into its half (ulp is 1 in [1024, 2048)); the bias cancels in d.
+// 16 + 16 + 8 instructions instead of the 79 of a two-input tree.  A byte b in a 16-bit half IS the fp16 subnormal
+// b * 2^-24 (gfx950 kernels run with fp16 subnormals enabled, .amdhsa_float_denorm_mode_16_64 3), differences and
+// min/max of such values are exact, and a non-negative result read back as an integer is the value again: no
+// conversion in either direction.
 typedef _Float16 hh2 __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ hh2 pkh(uint32_t lo, uint32_t hi) { return __builtin_bit_cast(hh2, (lo | (hi << 16)) | 0x64006400u); }
+__device__ __forceinline__ hh2 pkh(uint32_t lo, uint32_t hi) { return __builtin_bit_cast(hh2, lo | (hi << 16)); }
 __device__ __forceinline__ hh2 hmin3(hh2 a, hh2 b, hh2 c) { return __builtin_elementwise_minimum(__builtin_elementwise_minimum(a, b), c); }
 __device__ __forceinline__ hh2 hmax3(hh2 a, hh2 b, hh2 c) { return __builtin_elementwise_maximum(__builtin_elementwise_maximum(a, b), c); }
 
@@ -126,8 +128,9 @@ __device__ __forceinline__ void fast_stage2(const uint8_t *T0, const uint16_t *q
         const hh2 b3 = hmin3(m9[9], m9[10], m9[11]), b4 = hmin3(m9[12], m9[13], m9[14]);
         B = hmin3(hmin3(b0, b1, b2), hmin3(b3, b4, m9[15]), b0);
     }
-    const hh2 sc = __builtin_elementwise_maximum(A, -B);   // score + 1, an integer in [-255, 255]
-    const int s0 = (int)(float)sc.x - 1, s1 = (int)(float)sc.y - 1;
+    const hh2 zero = {(_Float16)0.0f, (_Float16)0.0f};
+    const uint32_t scb = __builtin_bit_cast(uint32_t, hmax3(A, -B, zero));   // (score + 1) * 2^-24 per half, clamped at 0
+    const int s0 = (int)(scb & 0xFFFFu) - 1, s1 = (int)(scb >> 16) - 1;
     if (s0 >= t_lo) { smap[__umul24((uint32_t)(pa >> 6) + 1u, (uint32_t)ZS) + (pa & 63) + 1] = (uint8_t)s0; *c0 = true; }
     if (two && s1 >= t_lo) { smap[__umul24((uint32_t)(pb >> 6) + 1u, (uint32_t)ZS) + (pb & 63) + 1] = (uint8_t)s1; *c1 = true; }
 }
