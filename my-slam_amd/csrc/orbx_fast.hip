@@ -180,30 +180,37 @@ __global__ __launch_bounds__(FAST_THREADS) void k_fast_cells(OrbxPlan plan, Orbx
     // ---- tile -> LDS.  Rows start at a 4-byte aligned address of the level (levels >= 1 always;
     // level 0 when the caller's base/strides are 4-byte multiples), so whole dwords are moved. ----
     const uint8_t *img = L.base + (long long)f * L.frame_stride + (long long)iniY * L.stride;
+    // Every tile is stored with its column 0 at LDS byte FAST_PADL + 1 of the row, whatever the alignment of iniX in
+    // memory: zone column 0 (tile column 3) then starts a dword, a zone row is exactly ceil(zw / 4) stage-1 groups
+    // (8 for the usual 31..32-px cells instead of 9..10) and no group hangs over the left edge.  The re-alignment is
+    // one v_alignbyte_b32 per dword moved.
     const bool bytes_only = (l == 0 && !l0_aligned);
-    const int xoff = bytes_only ? 0 : (iniX & 3);
     if (bytes_only) {
         for (int i = lane; i < tw * th; i += 64) {
             const int y = i / tw, x = i - y * tw;
-            S.tile[y * TS + FAST_PADL + x] = img[(long long)y * L.stride + iniX + x];
+            S.tile[y * TS + FAST_PADL + 1 + x] = img[(long long)y * L.stride + iniX + x];
         }
     } else {
         constexpr int NDW = TS / 4 - 2, RPP = 64 / NDW;   // payload dwords per tile row, rows per pass
-        const int ndw = (xoff + tw + 3) >> 2;
+        const int ndw = (tw + 4) >> 2;                    // LDS dwords 1 .. ndw hold tile columns -1 .. tw-1
         static_assert(NDW == 12 || NDW == 18, "lane / NDW below is written for these");
         const int r_in = NDW == 12 ? (int)(__umul24((uint32_t)lane, 43u) >> 9) : (int)(__umul24((uint32_t)lane, 57u) >> 10);   // lane / NDW, lane < 64
         const int cdw = lane - r_in * NDW;
-        const uint8_t *src = img + (iniX & ~3) + 4 * cdw;
+        const uint32_t sh = (uint32_t)(iniX - 1) & 3u;
+        const uint8_t *src = img + ((iniX - 1) & ~3) + 4 * cdw;   // the over-read of 4 bytes stays inside the image row (>= 10 bytes follow a tile)
         if (r_in < RPP && cdw < ndw) {
-            for (int r = r_in; r < th; r += RPP)
-                *reinterpret_cast<uint32_t *>(&S.tile[r * TS + FAST_PADL + 4 * cdw]) =
-                    *reinterpret_cast<const uint32_t *>(src + (long long)r * L.stride);
+            for (int r = r_in; r < th; r += RPP) {
+                const uint32_t *g2 = reinterpret_cast<const uint32_t *>(src + (long long)r * L.stride);
+                *reinterpret_cast<uint32_t *>(&S.tile[r * TS + FAST_PADL + 4 * cdw]) = __builtin_amdgcn_alignbyte(g2[1], g2[0], sh);
+            }
         }
     }
     FT(0);
-    const uint8_t *T0 = S.tile + FAST_PADL + xoff;   // tile origin (cell column 0)
-    const int cb = FAST_PADL + xoff + 3;             // tile byte column of zone column 0
-    const int g0 = cb >> 2, ng = ((cb + zw - 1) >> 2) - g0 + 1;
+    const uint8_t *T0 = S.tile + FAST_PADL + 1;      // tile origin (cell column 0)
+    constexpr int cb = FAST_PADL + 1 + 3;            // tile byte column of zone column 0: a dword boundary
+    static_assert((cb & 3) == 0, "zone column 0 must start a dword");
+    constexpr int g0 = cb >> 2;
+    const int ng = (zw + 3) >> 2;
     const uint32_t rcpg = (c_rcp20[ng] + 15u) >> 4;          // (1 << 16) / ng + 1 (or one more): t / ng for t < 1024, ng <= 16
     const int ntask = ng * zh;
 
@@ -241,7 +248,7 @@ __global__ __launch_bounds__(FAST_THREADS) void k_fast_cells(OrbxPlan plan, Orbx
             const int t = min(base + lane, ntask - 1);
             const int zy = (int)(__umul24((uint32_t)t, rcpg) >> 16);
             const int g = g0 + (t - (int)__umul24((uint32_t)zy, (uint32_t)ng));
-            const int zx0 = (base + lane < ntask) ? 4 * g - cb : -1000;   // zone column of byte 0 of this group
+            const int zx0 = (base + lane < ntask) ? 4 * g - cb : 1000;   // zone column of byte 0 of this group (>= 0)
             uint32_t f01, f23;
             {
                 const uint32_t *r0 = reinterpret_cast<const uint32_t *>(&S.tile[(zy + 3) * TS]) + g;
@@ -271,12 +278,11 @@ __global__ __launch_bounds__(FAST_THREADS) void k_fast_cells(OrbxPlan plan, Orbx
             // predicate costs two more vector instructions)
             const bool f0 = (f01 & 0x0000FFFFu) != 0, f1 = (f01 & 0xFFFF0000u) != 0;
             const bool f2 = (f23 & 0x0000FFFFu) != 0, f3 = (f23 & 0xFFFF0000u) != 0;
-            const bool l0 = zx0 >= 0, l1 = zx0 >= -1, l2 = zx0 >= -2, l3 = zx0 >= -3;
             const bool h0 = zx0 < zw, h1 = zx0 < zw - 1, h2 = zx0 < zw - 2, h3 = zx0 < zw - 3;
-            const bool k0 = f0 && l0 && h0, k1 = f1 && l1 && h1, k2 = f2 && l2 && h2, k3 = f3 && l3 && h3;
+            const bool k0 = f0 && h0, k1 = f1 && h1, k2 = f2 && h2, k3 = f3 && h3;
 #define BAL(P) __builtin_amdgcn_ballot_w64(P)
-            const unsigned long long b0 = BAL(f0) & BAL(l0) & BAL(h0), b1 = BAL(f1) & BAL(l1) & BAL(h1);
-            const unsigned long long b2 = BAL(f2) & BAL(l2) & BAL(h2), b3 = BAL(f3) & BAL(l3) & BAL(h3);
+            const unsigned long long b0 = BAL(f0) & BAL(h0), b1 = BAL(f1) & BAL(h1);
+            const unsigned long long b2 = BAL(f2) & BAL(h2), b3 = BAL(f3) & BAL(h3);
 #undef BAL
             const int n0 = __popcll(b0), n1 = __popcll(b1), n2 = __popcll(b2);
             const int e0 = orbx_prefix_cnt(b0, qn), e1 = orbx_prefix_cnt(b1, qn + n0);
