@@ -82,10 +82,15 @@ __device__ __forceinline__ void merge_partials(const uint2 *__restrict__ part, i
                                                int &bi, int &bd, int &sd)
 {
     uint32_t bk = M_KEY_NONE, sk = M_KEY_NONE;
-    for (int z = 0; z < S; z++) {
-        const uint2 p = part[(long long)z * stride_z + o];
-        sk = med3u(bk, sk, p.x); bk = min(bk, p.x);
-        sk = med3u(bk, sk, p.y); bk = min(bk, p.y);
+    for (int z0 = 0; z0 < S; z0 += 8) {   // eight partials per round trip (a load per iteration would be one memory latency each)
+        uint2 p[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) p[u] = z0 + u < S ? part[(long long)(z0 + u) * stride_z + o] : make_uint2(M_KEY_NONE, M_KEY_NONE);
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+            sk = med3u(bk, sk, p[u].x); bk = min(bk, p[u].x);
+            sk = med3u(bk, sk, p[u].y); bk = min(bk, p[u].y);
+        }
     }
     bd = (int)(bk >> 22);
     sd = (int)(sk >> 22);
