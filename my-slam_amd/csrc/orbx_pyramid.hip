@@ -81,10 +81,17 @@ __global__ __launch_bounds__(256) void k_resize_linear_4x4(
     for (int i = 1; i < 4; i++)
         if (x4 + i >= dw) { sx[i] = sx[0]; al[i] = al[0]; }
     const int base = sx[0];
-    const int k1 = 8 * (sx[1] - base), k2 = 8 * (sx[2] - base), k3 = 8 * (sx[3] - base);
+    // v_perm_b32 selectors: source bytes (sx[i] - base) and (sx[i] - base) + 1 of the 8-byte window into the two u16
+    // halves (0x0c = zero byte); the window offsets are < 7 by the planner's span check
+    uint32_t sel[4];
+#pragma unroll
+    for (int i = 0; i < 4; i++) sel[i] = 0x0c010c00u + (uint32_t)(sx[i] - base) * 0x00010001u;
 
     // phase 1: issue every load of the 4x4 block (8 row-table words, 24 source dwords) before any use,
-    // so one memory round trip covers the whole block instead of one per row
+    // so one memory round trip covers the whole block instead of one per row.  Addresses are the uniform frame base
+    // plus an unsigned 32-bit byte offset (one frame is below 2 GiB), which keeps the address arithmetic 32-bit.
+    const uint32_t s_lo = (uint32_t)(uintptr_t)S;
+    const uint32_t endoff = CHECK ? (uint32_t)(src_end - S) : 0u;   // only meaningful (and only used) for the last frame
     int b0v[4], b1v[4];
     uint32_t sh8[4][2], wv[4][2][3];
 #pragma unroll
@@ -97,13 +104,14 @@ __global__ __launch_bounds__(256) void k_resize_linear_4x4(
         const int sy0 = min(max(sy, 0), sh - 1), sy1 = min(max(sy + 1, 0), sh - 1);
 #pragma unroll
         for (int rr = 0; rr < 2; rr++) {
-            const uint8_t *p = S + (__mul24(rr ? sy1 : sy0, sstride) + base);   // offsets inside a frame fit 31 bits; 24-bit multiply is full rate
-            sh8[r][rr] = (uint32_t)((uintptr_t)p & 3u);
-            const uint32_t *q = reinterpret_cast<const uint32_t *>(p - sh8[r][rr]);
+            const uint32_t off = (uint32_t)(__mul24(rr ? sy1 : sy0, sstride) + base);   // 24-bit multiply is full rate
+            sh8[r][rr] = (s_lo + off) & 3u;
+            const uint32_t offa = off - sh8[r][rr];
+            const uint32_t *q = reinterpret_cast<const uint32_t *>(S + offa);
             if (CHECK && blockIdx.z == gridDim.z - 1) {   // only the last frame can end at the end of the caller's buffer
                 wv[r][rr][0] = q[0];
-                wv[r][rr][1] = (reinterpret_cast<const uint8_t *>(q + 2) <= src_end) ? q[1] : 0u;
-                wv[r][rr][2] = (reinterpret_cast<const uint8_t *>(q + 3) <= src_end) ? q[2] : 0u;
+                wv[r][rr][1] = (offa + 8u <= endoff) ? q[1] : 0u;
+                wv[r][rr][2] = (offa + 12u <= endoff) ? q[2] : 0u;
             } else {
                 wv[r][rr][0] = q[0]; wv[r][rr][1] = q[1]; wv[r][rr][2] = q[2];
             }
@@ -120,13 +128,10 @@ __global__ __launch_bounds__(256) void k_resize_linear_4x4(
         for (int rr = 0; rr < 2; rr++) {
             const uint32_t lo = __builtin_amdgcn_alignbyte(wv[r][rr][1], wv[r][rr][0], sh8[r][rr]);
             const uint32_t hi = __builtin_amdgcn_alignbyte(wv[r][rr][2], wv[r][rr][1], sh8[r][rr]);
-            const unsigned long long w64 = ((unsigned long long)hi << 32) | lo;
-            const uint32_t t0 = lo, t1 = (uint32_t)(w64 >> k1), t2 = (uint32_t)(w64 >> k2), t3 = (uint32_t)(w64 >> k3);
             // (S[sx] | S[sx+1] << 16) . (a0 | a1 << 16)
-            hv[rr][0] = (int)__builtin_amdgcn_udot2(__builtin_bit_cast(us2, __builtin_amdgcn_perm(0u, t0, 0x0c010c00u)), __builtin_bit_cast(us2, al[0]), 0u, false);
-            hv[rr][1] = (int)__builtin_amdgcn_udot2(__builtin_bit_cast(us2, __builtin_amdgcn_perm(0u, t1, 0x0c010c00u)), __builtin_bit_cast(us2, al[1]), 0u, false);
-            hv[rr][2] = (int)__builtin_amdgcn_udot2(__builtin_bit_cast(us2, __builtin_amdgcn_perm(0u, t2, 0x0c010c00u)), __builtin_bit_cast(us2, al[2]), 0u, false);
-            hv[rr][3] = (int)__builtin_amdgcn_udot2(__builtin_bit_cast(us2, __builtin_amdgcn_perm(0u, t3, 0x0c010c00u)), __builtin_bit_cast(us2, al[3]), 0u, false);
+#pragma unroll
+            for (int i = 0; i < 4; i++)
+                hv[rr][i] = (int)__builtin_amdgcn_udot2(__builtin_bit_cast(us2, __builtin_amdgcn_perm(hi, lo, sel[i])), __builtin_bit_cast(us2, al[i]), 0u, false);
         }
         uint32_t out = 0;
 #pragma unroll
@@ -135,7 +140,7 @@ __global__ __launch_bounds__(256) void k_resize_linear_4x4(
             const int v = ((__mul24(b0, hv[0][i] >> 4) >> 16) + (__mul24(b1, hv[1][i] >> 4) >> 16) + 2) >> 2;
             out |= (uint32_t)(v & 255) << (8 * i);
         }
-        uint8_t *Dr = D + (__mul24(y, dstride) + x4);
+        uint8_t *Dr = D + (uint32_t)(__mul24(y, dstride) + x4);
         if (x4 + 3 < dw) *reinterpret_cast<uint32_t *>(Dr) = out;
         else
             for (int i = 0; x4 + i < dw; i++) Dr[i] = (uint8_t)(out >> (8 * i));
