@@ -27,6 +27,23 @@ def test_extract_matches_oracle(orbx, synth, W, H, n):
     _compare(kps, desc, okps, odesc, "%dx%d" % (W, H))
 
 
+@pytest.mark.parametrize("W,H,n,seed,what", [
+    (1024, 768, 3000, 31, "512-thread quadtree, > 6144 level-0 candidates: keys in global memory"),
+    (1920, 1080, 600, 32, "1024-thread quadtree, few features: tiny lists, phase B early"),
+    (1600, 1200, 6000, 33, "1024-thread quadtree, 32 keys per thread"),
+    (200, 150, 3000, 34, "more features requested than candidates exist"),
+])
+def test_quadtree_key_storage_tiers(orbx, synth, W, H, n, seed, what):
+    """k_octree keeps the keys in registers (8 / 12 / 32 per thread) or, beyond that, in global memory."""
+    img = synth.texture(seed, W, H)
+    ex = orbx.ORBextractor(n, 1.2, 8, 20, 7, max_width=W, max_height=H)
+    kps, desc = ex(img)
+    okps, odesc, _ = O.Extractor(n).extract(img)
+    _compare(kps, desc, okps, odesc, what)
+    if W == 1024:
+        assert len(ex.candidates(0, 0)) > 6144, "case no longer reaches the global-memory key path"
+
+
 def test_pyramid_and_candidates_match_oracle(orbx, synth):
     W, H = 640, 480
     img = synth.texture(7, W, H)
