@@ -111,6 +111,25 @@ int orbm_search_area_best2_device(orbm_matcher *m, const uint8_t *d_qdesc, const
                                   const uint8_t *d_train_desc, const uint8_t *d_skip,
                                   int32_t *d_best_idx, int32_t *d_best_d, int32_t *d_second_d, void *hip_stream);
 
+/*
+ * ---- "next" row N2: ORBmatcher::SearchByBoW(KeyFrame*, Frame&, ...) src/ORBmatcher.cc:159-288 ----
+ * The two FeatureVectors come from orbv_feature_vector (ascending node ids, CSR feature lists).  For every node both
+ * frames share, every key-frame feature with a usable MapPoint (valid_kf[i] != 0: the reference's `pMP && !pMP->isBad()`)
+ * scans the frame's features of that node in list order, skipping the ones an earlier key-frame feature already took
+ * (`if(vpMapPointMatches[realIdxF]) continue;` :209) -- so the scan order matters and is kept: the Hamming distances of
+ * all (key-frame feature, frame feature) pairs of the shared nodes are computed in one GPU call, the sequential
+ * best / second-best selection (:214-246), the TH_LOW and ratio tests and the rotation histogram (:236-246, :266-284)
+ * run on the host on those distances.  match_f[i] = index of the key-frame feature matched to frame feature i, or -1
+ * (the reference's vpMapPointMatches as indices); *nmatches = the function's return value.
+ * kps_kf are the key frame's mvKeysUn, kps_f the frame's mvKeys (only .angle is read).
+ */
+int orbm_search_by_bow(orbm_matcher *m,
+                       const uint8_t *desc_kf, const orbx_keypoint *kps_kf, int n_kf, const uint8_t *valid_kf,
+                       const int32_t *fv_kf_node, const int32_t *fv_kf_off, const int32_t *fv_kf_idx, int fv_kf_n,
+                       const uint8_t *desc_f, const orbx_keypoint *kps_f, int n_f,
+                       const int32_t *fv_f_node, const int32_t *fv_f_off, const int32_t *fv_f_idx, int fv_f_n,
+                       float nnratio, int check_orientation, int32_t *match_f, int *nmatches);
+
 /* Host helpers: ComputeThreeMaxima (ind[3], -1 = none) and the histogram cull over match12. */
 int orbm_three_maxima(const int32_t *hist_sizes, int L, int32_t ind[3]);
 int orbm_rot_filter(const float *angle_q, const float *angle_t, int32_t *match12, int nq);

@@ -128,6 +128,8 @@ def _bind_matcher(L):
     L.orbm_search_area_best2.argtypes = [vp, vp, vp, vp, vp, vp, vp, C.c_int, vp, vp, vp, vp, vp]
     L.orbm_search_area_best2_device.argtypes = [vp, vp, vp, vp, vp, vp, vp, C.c_int, vp, vp, vp, vp, vp, vp]
     L.orbm_rot_filter.argtypes = [vp, vp, vp, C.c_int]
+    L.orbm_search_by_bow.argtypes = [vp, vp, vp, C.c_int, vp, vp, vp, vp, C.c_int,
+                                     vp, vp, C.c_int, vp, vp, vp, C.c_int, C.c_float, C.c_int, vp, vp]
     L.orbm_three_maxima.argtypes = [vp, C.c_int, vp]
     L.orbm_last_error.restype = C.c_char_p
     for name in ("orbm_create", "orbm_distance", "orbm_best2", "orbm_distances", "orbm_best2_batch_device",
@@ -390,6 +392,24 @@ class ORBmatcher:
         _mchk(self.L.orbm_search_area_best2(self.h, _p(qdesc), _p(x), _p(y), _p(r), _p(mn), _p(mx), nq, _p(train_desc), _p(skip),
                                             _p(bi), _p(bd), _p(sd)))
         return bi, bd, sd
+
+    def SearchByBoW(self, kps_kf, desc_kf, featvec_kf, kps_f, desc_f, featvec_f, valid_kf=None):
+        """ORBmatcher::SearchByBoW(KeyFrame*, Frame&, vpMapPointMatches) (src/ORBmatcher.cc:159-288).  featvec_* are the
+        (node ids, offsets, indices) triples of ORBVocabulary.transform; returns (match_f, nmatches) with match_f[i] =
+        key-frame feature matched to frame feature i or -1."""
+        desc_kf = np.ascontiguousarray(desc_kf, np.uint8).reshape(-1, 32)
+        desc_f = np.ascontiguousarray(desc_f, np.uint8).reshape(-1, 32)
+        kps_kf = np.ascontiguousarray(kps_kf); kps_f = np.ascontiguousarray(kps_f)
+        nk, ok, ik = [np.ascontiguousarray(a, np.int32) for a in featvec_kf]
+        nf, of, i_f = [np.ascontiguousarray(a, np.int32) for a in featvec_f]
+        if valid_kf is not None:
+            valid_kf = np.ascontiguousarray(valid_kf, np.uint8)
+        match_f = np.full(len(desc_f), -1, np.int32)
+        nm = C.c_int(0)
+        _mchk(self.L.orbm_search_by_bow(self.h, _p(desc_kf), _p(kps_kf), len(desc_kf), _p(valid_kf), _p(nk), _p(ok), _p(ik), len(nk),
+                                        _p(desc_f), _p(kps_f), len(desc_f), _p(nf), _p(of), _p(i_f), len(nf),
+                                        C.c_float(self.mfNNratio), 1 if self.mbCheckOrientation else 0, _p(match_f), C.byref(nm)))
+        return match_f, nm.value
 
 
 class ORBVocabulary:

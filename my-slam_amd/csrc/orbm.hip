@@ -519,6 +519,107 @@ extern "C" int orbm_best2_batch_device(orbm_matcher *m, const uint8_t *d_q, cons
 }
 
 // ---- host helpers (ComputeThreeMaxima :1601-1642, histogram fill/cull :236-246,:266-284) ----
+// ---- N2: SearchByBoW (src/ORBmatcher.cc:159-288): distances on the GPU, the order-dependent selection on the host ----
+extern "C" int orbm_search_by_bow(orbm_matcher *m,
+                                  const uint8_t *desc_kf, const orbx_keypoint *kps_kf, int n_kf, const uint8_t *valid_kf,
+                                  const int32_t *fv_kf_node, const int32_t *fv_kf_off, const int32_t *fv_kf_idx, int fv_kf_n,
+                                  const uint8_t *desc_f, const orbx_keypoint *kps_f, int n_f,
+                                  const int32_t *fv_f_node, const int32_t *fv_f_off, const int32_t *fv_f_idx, int fv_f_n,
+                                  float nnratio, int check_orientation, int32_t *match_f, int *nmatches)
+{
+    if (!m) return mfail(ORBX_E_INVALID, "NULL handle");
+    if (n_kf < 0 || n_f < 0 || fv_kf_n < 0 || fv_f_n < 0 || !match_f || !nmatches) return mfail(ORBX_E_INVALID, "bad argument");
+    *nmatches = 0;
+    for (int i = 0; i < n_f; i++) match_f[i] = -1;
+    if (n_kf == 0 || n_f == 0 || fv_kf_n == 0 || fv_f_n == 0) return ORBX_OK;
+    if (!desc_kf || !kps_kf || !desc_f || !kps_f || !fv_kf_node || !fv_kf_off || !fv_kf_idx || !fv_f_node || !fv_f_off || !fv_f_idx)
+        return mfail(ORBX_E_INVALID, "NULL buffer");
+    if (n_f > m->max_t) return mfail(ORBX_E_CAPACITY, "n_f=%d exceeds the matcher's max_train=%d", n_f, m->max_t);
+    // merge-join of the two ascending node lists (:178-262); queries = usable key-frame features in visiting order
+    struct Q { int kf, f_node; };
+    std::vector<Q> qs;
+    std::vector<int32_t> off(1, 0);
+    std::vector<uint8_t> qdesc;
+    long long pairs = 0;
+    for (int a = 0, b = 0; a < fv_kf_n && b < fv_f_n;) {
+        if (fv_kf_node[a] == fv_f_node[b]) {
+            const int nb = fv_f_off[b + 1] - fv_f_off[b];
+            for (int c = fv_kf_off[a]; c < fv_kf_off[a + 1]; c++) {
+                const int ikf = fv_kf_idx[c];
+                if (ikf < 0 || ikf >= n_kf) return mfail(ORBX_E_INVALID, "key-frame feature index %d outside [0,%d)", ikf, n_kf);
+                if (valid_kf && !valid_kf[ikf]) continue;
+                qs.push_back({ikf, b});
+                pairs += nb;
+                off.push_back((int32_t)pairs);
+                qdesc.insert(qdesc.end(), desc_kf + (size_t)ikf * 32, desc_kf + (size_t)ikf * 32 + 32);
+            }
+            a++; b++;
+        } else if (fv_kf_node[a] < fv_f_node[b]) a++;   // lower_bound on an ascending list == advance
+        else b++;
+    }
+    const int nq = (int)qs.size();
+    if (nq == 0 || pairs == 0) return ORBX_OK;
+    if (nq > m->max_q) return mfail(ORBX_E_CAPACITY, "%d key-frame features to match, matcher sized for %d queries", nq, m->max_q);
+    if (pairs > m->max_pairs) return mfail(ORBX_E_CAPACITY, "%lld candidate pairs, matcher sized for %d", pairs, m->max_pairs);
+    std::vector<int32_t> idx((size_t)pairs), dist((size_t)pairs);
+    for (int i = 0; i < nq; i++) {
+        const int b = qs[i].f_node;
+        int32_t *dst = idx.data() + off[i];
+        for (int c = fv_f_off[b]; c < fv_f_off[b + 1]; c++) {
+            const int fi = fv_f_idx[c];
+            if (fi < 0 || fi >= n_f) return mfail(ORBX_E_INVALID, "frame feature index %d outside [0,%d)", fi, n_f);
+            *dst++ = fi;
+        }
+    }
+    MHIPCHK(hipSetDevice(m->device));
+    hipStream_t s = m->stream;
+    MHIPCHK(hipMemcpyAsync(m->d_q, qdesc.data(), (size_t)nq * 32, hipMemcpyHostToDevice, s));
+    MHIPCHK(hipMemcpyAsync(m->d_t, desc_f, (size_t)n_f * 32, hipMemcpyHostToDevice, s));
+    MHIPCHK(hipMemcpyAsync(m->d_off, off.data(), ((size_t)nq + 1) * 4, hipMemcpyHostToDevice, s));
+    MHIPCHK(hipMemcpyAsync(m->d_idx, idx.data(), (size_t)pairs * 4, hipMemcpyHostToDevice, s));
+    hipLaunchKernelGGL(k_dist_csr, dim3((unsigned)((pairs + M_THREADS - 1) / M_THREADS)), dim3(M_THREADS), 0, s,
+                       m->d_q, nq, m->d_t, m->d_off, m->d_idx, (int)pairs, m->d_out);
+    MHIPCHK(hipGetLastError());
+    MHIPCHK(hipMemcpyAsync(dist.data(), m->d_out, (size_t)pairs * 4, hipMemcpyDeviceToHost, s));
+    MHIPCHK(hipStreamSynchronize(s));
+    // sequential selection (:199-246)
+    int32_t hist[ORBM_HISTO_LENGTH] = {0};
+    std::vector<int> bin_of((size_t)n_f, -1);
+    const float factor = 1.0f / ORBM_HISTO_LENGTH;
+    int nm = 0;
+    for (int i = 0; i < nq; i++) {
+        int best1 = 256, best2 = 256, bestF = -1;
+        for (int c = off[i]; c < off[i + 1]; c++) {
+            const int fi = idx[c];
+            if (match_f[fi] >= 0) continue;                 // :209
+            const int d = dist[c];
+            if (d < best1) { best2 = best1; best1 = d; bestF = fi; }
+            else if (d < best2) best2 = d;
+        }
+        if (best1 <= ORBM_TH_LOW && (float)best1 < nnratio * (float)best2) {
+            match_f[bestF] = qs[i].kf;
+            if (check_orientation) {
+                float rot = kps_kf[qs[i].kf].angle - kps_f[bestF].angle;
+                if (rot < 0.0) rot += 360.0f;
+                int bin = (int)roundf(rot * factor);
+                if (bin == ORBM_HISTO_LENGTH) bin = 0;
+                if (bin < 0 || bin >= ORBM_HISTO_LENGTH) return mfail(ORBX_E_INVALID, "keypoint angle outside [0, 360)");   // the reference asserts
+                bin_of[bestF] = bin;
+                hist[bin]++;
+            }
+            nm++;
+        }
+    }
+    if (check_orientation) {
+        int32_t ind[3];
+        orbm_three_maxima(hist, ORBM_HISTO_LENGTH, ind);
+        for (int i = 0; i < n_f; i++)
+            if (bin_of[i] >= 0 && bin_of[i] != ind[0] && bin_of[i] != ind[1] && bin_of[i] != ind[2]) { match_f[i] = -1; nm--; }
+    }
+    *nmatches = nm;
+    return ORBX_OK;
+}
+
 extern "C" int orbm_three_maxima(const int32_t *histo, int L, int32_t ind[3])
 {
     if (!histo || !ind || L < 0) return mfail(ORBX_E_INVALID, "bad argument");

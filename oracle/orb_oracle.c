@@ -1272,3 +1272,67 @@ double oro_voc_score_l1(const int32_t *ids1, const double *vals1, int n1, const 
     }
     return -score / 2.0;
 }
+
+/* ORBmatcher::SearchByBoW(KeyFrame*, Frame&, vpMapPointMatches) src/ORBmatcher.cc:159-288, with MapPoint pointers
+ * replaced by key-frame feature indices (match_f[i] = KF feature matched to frame feature i, -1 = NULL) and
+ * `pMP && !pMP->isBad()` by valid_kf[].  FeatureVectors as (ascending node ids, CSR lists), the std::map's order. */
+int oro_search_by_bow(const uint8_t *desc_kf, const float *angle_kf, int n_kf, const uint8_t *valid_kf,
+                      const int32_t *kf_node, const int32_t *kf_off, const int32_t *kf_idx, int kf_n,
+                      const uint8_t *desc_f, const float *angle_f, int n_f,
+                      const int32_t *f_node, const int32_t *f_off, const int32_t *f_idx, int f_n,
+                      float nnratio, int check_orientation, int32_t *match_f)
+{
+    int nmatches = 0;
+    int *rot_items = (int *)malloc(sizeof(int) * (size_t)(n_f > 0 ? n_f : 1) * 2);   /* (bin, frame feature) in push order */
+    int nrot = 0;
+    int hist[30];
+    (void)n_kf;
+    for (int i = 0; i < 30; i++) hist[i] = 0;
+    for (int i = 0; i < n_f; i++) match_f[i] = -1;                                   /* :163 */
+    int a = 0, b = 0;
+    while (a < kf_n && b < f_n) {                                                    /* :180 */
+        if (kf_node[a] == f_node[b]) {
+            for (int ik = kf_off[a]; ik < kf_off[a + 1]; ik++) {                      /* :187 */
+                const int realIdxKF = kf_idx[ik];
+                if (valid_kf && !valid_kf[realIdxKF]) continue;                      /* :193-197 */
+                const uint8_t *dKF = desc_kf + (size_t)realIdxKF * 32;
+                int bestDist1 = 256, bestIdxF = -1, bestDist2 = 256;
+                for (int jf = f_off[b]; jf < f_off[b + 1]; jf++) {                    /* :205 */
+                    const int realIdxF = f_idx[jf];
+                    if (match_f[realIdxF] >= 0) continue;                            /* :209 */
+                    const int dist = oro_descriptor_distance(dKF, desc_f + (size_t)realIdxF * 32);
+                    if (dist < bestDist1) { bestDist2 = bestDist1; bestDist1 = dist; bestIdxF = realIdxF; }
+                    else if (dist < bestDist2) bestDist2 = dist;
+                }
+                if (bestDist1 <= 50) {                                               /* TH_LOW :228 */
+                    if ((float)bestDist1 < nnratio * (float)bestDist2) {             /* :230 */
+                        match_f[bestIdxF] = realIdxKF;
+                        if (check_orientation) {
+                            const int bin = oro_rot_bin(angle_kf[realIdxKF], angle_f[bestIdxF]);
+                            rot_items[2 * nrot] = bin; rot_items[2 * nrot + 1] = bestIdxF; nrot++;
+                            hist[bin]++;
+                        }
+                        nmatches++;
+                    }
+                }
+            }
+            a++; b++;
+        } else if (kf_node[a] < f_node[b]) {
+            a++;                                                                     /* lower_bound(Fit->first) :253 */
+        } else {
+            b++;
+        }
+    }
+    if (check_orientation) {                                                         /* :266-284 */
+        int ind1, ind2, ind3;
+        oro_three_maxima(hist, 30, &ind1, &ind2, &ind3);
+        for (int k = 0; k < nrot; k++) {
+            const int bin = rot_items[2 * k];
+            if (bin == ind1 || bin == ind2 || bin == ind3) continue;
+            match_f[rot_items[2 * k + 1]] = -1;
+            nmatches--;
+        }
+    }
+    free(rot_items);
+    return nmatches;
+}

@@ -175,6 +175,12 @@ void oro_voc_transform_features(const oro_voc *v, const uint8_t *feat, int n, in
 int oro_voc_bow_vector(const oro_voc *v, const int32_t *word_id, const double *weight, int n, int32_t *ids, double *vals);
 int oro_voc_feature_vector(const int32_t *node_id, const double *weight, int n, int32_t *node_ids, int32_t *off, int32_t *idx);
 double oro_voc_score_l1(const int32_t *ids1, const double *vals1, int n1, const int32_t *ids2, const double *vals2, int n2);
+/* ORBmatcher::SearchByBoW(KeyFrame*, Frame&, ...) src/ORBmatcher.cc:159-288 on feature indices; returns nmatches */
+int oro_search_by_bow(const uint8_t *desc_kf, const float *angle_kf, int n_kf, const uint8_t *valid_kf,
+                      const int32_t *kf_node, const int32_t *kf_off, const int32_t *kf_idx, int kf_n,
+                      const uint8_t *desc_f, const float *angle_f, int n_f,
+                      const int32_t *f_node, const int32_t *f_off, const int32_t *f_idx, int f_n,
+                      float nnratio, int check_orientation, int32_t *match_f);
 
 #ifdef __cplusplus
 }

@@ -88,6 +88,9 @@ def lib(native=False):
                                      C.POINTER(C.c_int), C.POINTER(C.c_int), C.c_float, C.c_float, vp, vp]
     L.oro_stereo_matches.restype = None
     L.oro_match_dense.argtypes = [vp, vp, C.c_int, vp, vp, C.c_int, C.c_int, C.c_float, C.c_int, vp]
+    L.oro_search_by_bow.argtypes = [vp, vp, C.c_int, vp, vp, vp, vp, C.c_int, vp, vp, C.c_int, vp, vp, vp, C.c_int,
+                                    C.c_float, C.c_int, vp]
+    L.oro_search_by_bow.restype = C.c_int
     L.oro_match_dense.restype = C.c_int
     if not native:
         _lib = L
@@ -186,6 +189,22 @@ def best2(q, t, cand_off=None, cand_idx=None):
     else:
         L.oro_best2(_p(q), nq, _p(t), nt, None, None, _p(bi), _p(bd), _p(sd))
     return bi, bd, sd
+
+
+def search_by_bow(desc_kf, angle_kf, featvec_kf, desc_f, angle_f, featvec_f, nnratio=0.7, check_ori=True, valid_kf=None):
+    """ORBmatcher::SearchByBoW on feature indices (oracle)."""
+    L = lib()
+    desc_kf = np.ascontiguousarray(desc_kf, np.uint8); desc_f = np.ascontiguousarray(desc_f, np.uint8)
+    angle_kf = np.ascontiguousarray(angle_kf, np.float32); angle_f = np.ascontiguousarray(angle_f, np.float32)
+    nk, ok, ik = [np.ascontiguousarray(a, np.int32) for a in featvec_kf]
+    nf, of, i_f = [np.ascontiguousarray(a, np.int32) for a in featvec_f]
+    v = None if valid_kf is None else np.ascontiguousarray(valid_kf, np.uint8)
+    match_f = np.full(len(desc_f), -1, np.int32)
+    p = lambda a: None if a is None else a.ctypes.data
+    nm = L.oro_search_by_bow(p(desc_kf), p(angle_kf), len(desc_kf), p(v), p(nk), p(ok), p(ik), len(nk),
+                             p(desc_f), p(angle_f), len(desc_f), p(nf), p(of), p(i_f), len(nf),
+                             C.c_float(nnratio), 1 if check_ori else 0, p(match_f))
+    return match_f, nm
 
 
 def match_dense(q, aq, t, at, th=50, nnratio=0.9, check_ori=True):

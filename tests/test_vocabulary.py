@@ -147,3 +147,32 @@ def test_search_by_bow_buckets(orbx, synth, tmp_path):
     obi, obd, osd = O.best2(d0[q_idx], d1, np.array(off, np.int32), np.array(idx, np.int32))
     assert np.array_equal(bi, obi) and np.array_equal(bd, obd) and np.array_equal(sd, osd)
     assert ((bd <= 50) & (bd < 0.7 * sd)).sum() > 50
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("nnratio,check_ori,with_valid", [(0.7, True, False), (0.9, False, True), (0.6, True, True)])
+def test_search_by_bow_equals_oracle(orbx, synth, tmp_path, nnratio, check_ori, with_valid):
+    """orbm_search_by_bow == ORBmatcher::SearchByBoW restated (order-dependent skip of already matched frame features,
+    TH_LOW, ratio test, rotation histogram): same match table and the same return value."""
+    path = str(tmp_path / "voc.txt")
+    make_vocabulary(path, 10, 3, seed=9)
+    v = orbx.ORBVocabulary(path)
+    f0, f1 = synth.frame_pair(3, 640, 480)
+    ex = orbx.ORBextractor(1000, max_width=640, max_height=480)
+    k0, d0 = ex(f0); k1, d1 = ex(f1)
+    _, fv0 = v.transform(d0, 2)
+    _, fv1 = v.transform(d1, 2)
+    valid = None
+    if with_valid:
+        valid = (np.random.default_rng(1).random(len(d0)) < 0.7).astype(np.uint8)   # some key-frame features without a MapPoint
+    m = orbx.ORBmatcher(nnratio, check_ori, max_queries=4096, max_train=4096, max_pairs=1 << 20)
+    mf, nm = m.SearchByBoW(k0, d0, fv0, k1, d1, fv1, valid)
+    omf, onm = O.search_by_bow(d0, k0["angle"], fv0, d1, k1["angle"], fv1, nnratio, check_ori, valid)
+    assert nm == onm and np.array_equal(mf, omf)
+    assert nm > 40 and nm == int((mf >= 0).sum())
+    if with_valid:
+        assert valid[mf[mf >= 0]].all()
+    # degenerate inputs
+    e = (np.zeros(0, np.int32), np.zeros(1, np.int32), np.zeros(0, np.int32))
+    mf2, nm2 = m.SearchByBoW(k0, d0, e, k1, d1, fv1)
+    assert nm2 == 0 and (mf2 == -1).all()

@@ -2,7 +2,7 @@
 """BASELINE config 5 shape without the pose solvers: a Tracking-shaped per-frame loop on 1241x376 synthetic frames
 (KITTI-odometry-seq-00 shape), nFeatures = 2000:
     extract (GPU) -> Frame grid (GPU) -> ComputeBoW (GPU descent + host maps)
-    -> TrackReferenceKeyFrame-style SearchByBoW buckets (GPU best2, TH_LOW, ratio 0.7, rotation filter)
+    -> TrackReferenceKeyFrame's ORBmatcher::SearchByBoW (orbm_search_by_bow: TH_LOW, ratio 0.7, rotation filter)
     -> TrackWithMotionModel-style windowed search around the previous positions (GPU, TH_HIGH, rotation filter)
 EPnP RANSAC and g2o pose optimisation (src/PnPsolver.cc, src/Optimizer.cc) are host-side dense fp64 solves and are
 not part of this repository; the harness reports the front-end + matching time per frame.
@@ -34,19 +34,11 @@ for k in range(K):
     bow, fv = voc.transform(de, 2); t3 = time.perf_counter()
     if prev is not None:
         pk, pd, pfv = prev
-        # SearchByBoW: merge-join of the two FeatureVectors -> CSR lists -> best2 -> acceptance
-        n0, o0, i0 = pfv; n1, o1, i1 = fv
-        common, ia, ib = np.intersect1d(n0, n1, return_indices=True)
-        q_idx, off, idx = [], [0], []
-        for a, b in zip(ia, ib):
-            cb = i1[o1[b]:o1[b + 1]]
-            for qa in i0[o0[a]:o0[a + 1]]:
-                q_idx.append(qa); idx.append(cb); off.append(off[-1] + len(cb))
-        q_idx = np.array(q_idx, np.int64)
-        bi, bd, sd = mt.best2(pd[q_idx], de, np.array(off, np.int32), np.concatenate(idx).astype(np.int32) if idx else np.zeros(0, np.int32))
-        m12 = np.where((bd <= 50) & (bd.astype(np.float32) < np.float32(0.7) * sd.astype(np.float32)), bi, -1).astype(np.int32)
-        aq = np.ascontiguousarray(pk["angle"][q_idx]); at = np.ascontiguousarray(kp["angle"])
-        nm_bow += mt.L.orbm_rot_filter(aq.ctypes.data, at.ctypes.data, m12.ctypes.data, len(m12))
+        # TrackReferenceKeyFrame: ORBmatcher::SearchByBoW(KeyFrame*, Frame&, ...) with the reference's exact semantics
+        # (distances of all node-mates on the GPU, the order-dependent selection on the host, inside the library)
+        _, n_bow = mt.SearchByBoW(pk, pd, pfv, kp, de, fv)
+        nm_bow += n_bow
+        at = np.ascontiguousarray(kp["angle"])
         t4 = time.perf_counter()
         # TrackWithMotionModel shape: window 15 * scale around the previous position, octave +-1, TH_HIGH
         r = (15.0 * np.float32(1.2) ** pk["octave"]).astype(np.float32)
