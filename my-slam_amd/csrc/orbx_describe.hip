@@ -324,8 +324,13 @@ __global__ __launch_bounds__(256) void k_describe(
     ORBX_TRACE_STAMP(1);
     // ---- 7x7 Gaussian, row pass (exact, <= 65535), two rows per task, packed vertically ----
     const uint32_t k0 = (uint32_t)c_gauss[0], k1 = (uint32_t)c_gauss[1], k2 = (uint32_t)c_gauss[2], k3 = (uint32_t)c_gauss[3];
-    const uint32_t KA = k0 | (k1 << 8) | (k2 << 16) | (k3 << 24);     // taps 0..3
-    const uint32_t KB = k2 | (k1 << 8) | (k0 << 16);                  // taps 4..6 (symmetric kernel), tap 7 = 0
+    // Output j of a group is the 7-tap window at bytes j .. j+6 of the 12 bytes (w0, w1, w2).  Instead of shifting the
+    // window into place (v_alignbyte_b32) the taps are shifted: one packed-tap constant per (j, dword) -- 2 + 2 + 3 + 3
+    // v_dot4_u32_u8 for the four outputs and no byte shuffles.  Taps are symmetric: k4 = k2, k5 = k1, k6 = k0.
+    const uint32_t T0a = k0 | (k1 << 8) | (k2 << 16) | (k3 << 24), T0b = k2 | (k1 << 8) | (k0 << 16);
+    const uint32_t T1a = (k0 << 8) | (k1 << 16) | (k2 << 24),      T1b = k3 | (k2 << 8) | (k1 << 16) | (k0 << 24);
+    const uint32_t T2a = (k0 << 16) | (k1 << 24),                  T2b = k2 | (k3 << 8) | (k2 << 16) | (k1 << 24), T2c = k0;
+    const uint32_t T3a = (k0 << 24),                               T3b = k1 | (k2 << 8) | (k3 << 16) | (k2 << 24), T3c = k1 | (k0 << 8);
     static_assert(DW_P_STRIDE == 40 && DW_BL_STRIDE == 40 && DESC_R == DESC_R_H, "task tables");
 #pragma unroll
     for (int it = 0; it < 3; it++) {
@@ -336,14 +341,18 @@ __global__ __launch_bounds__(256) void k_describe(
             const uint32_t a0 = ra[0], a1 = ra[1], a2 = ra[2];
             const uint32_t b0 = rbp[0], b1 = rbp[1], b2 = rbp[2];
             uint32_t o[4];
-#define ROWOUT(J, LOW0, LOW1, LOW2)                                                                             \
-    (__builtin_amdgcn_udot4((J) == 0 ? LOW0 : __builtin_amdgcn_alignbyte(LOW1, LOW0, (J)), KA,                  \
-                            __builtin_amdgcn_udot4((J) == 0 ? LOW1 : __builtin_amdgcn_alignbyte(LOW2, LOW1, (J)), KB, 0u, false), false))
-            o[0] = ROWOUT(0, a0, a1, a2) | (ROWOUT(0, b0, b1, b2) << 16);
-            o[1] = ROWOUT(1, a0, a1, a2) | (ROWOUT(1, b0, b1, b2) << 16);
-            o[2] = ROWOUT(2, a0, a1, a2) | (ROWOUT(2, b0, b1, b2) << 16);
-            o[3] = ROWOUT(3, a0, a1, a2) | (ROWOUT(3, b0, b1, b2) << 16);
-#undef ROWOUT
+#define DOT4(A, K, ACC) __builtin_amdgcn_udot4((A), (K), (ACC), false)
+#define ROW4(W0, W1, W2, R0, R1, R2, R3)                                   \
+    R0 = DOT4(W0, T0a, DOT4(W1, T0b, 0u));                                 \
+    R1 = DOT4(W0, T1a, DOT4(W1, T1b, 0u));                                 \
+    R2 = DOT4(W0, T2a, DOT4(W1, T2b, DOT4(W2, T2c, 0u)));                  \
+    R3 = DOT4(W0, T3a, DOT4(W1, T3b, DOT4(W2, T3c, 0u)));
+            uint32_t ra0, ra1, ra2, ra3, rb0, rb1, rb2, rb3;
+            ROW4(a0, a1, a2, ra0, ra1, ra2, ra3)
+            ROW4(b0, b1, b2, rb0, rb1, rb2, rb3)
+#undef ROW4
+#undef DOT4
+            o[0] = ra0 | (rb0 << 16); o[1] = ra1 | (rb1 << 16); o[2] = ra2 | (rb2 << 16); o[3] = ra3 | (rb3 << 16);
             *reinterpret_cast<uint4 *>(&S.P[te >> 16]) = make_uint4(o[0], o[1], o[2], o[3]);
         }
     }
