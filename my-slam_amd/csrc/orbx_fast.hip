@@ -330,10 +330,12 @@ __global__ __launch_bounds__(FAST_THREADS) void k_fast_cells(OrbxPlan plan, Orbx
                 if (cl_over) { y = (int)(__umul24((uint32_t)idx, rcp) >> 20); x = idx - (int)__umul24((uint32_t)y, (uint32_t)zw); }
                 else { const int pos = S.clist[idx]; y = pos >> 6; x = pos & 63; }
                 const uint8_t *q = &S.smap[__umul24((uint32_t)y + 1u, (uint32_t)ZS) + x + 1];
-                const int s = q[0];
-                if (s > 0)
-                    ismax = s > q[-1] && s > q[1] && s > q[-ZS - 1] && s > q[-ZS] && s > q[-ZS + 1] &&
-                            s > q[ZS - 1] && s > q[ZS] && s > q[ZS + 1];
+                // all nine reads at once and one comparison against the neighbours' maximum (v_max3_u32): a chain of &&
+                // would turn into eight divergent branches
+                const uint32_t s = q[0];
+                const uint32_t n0 = q[-1], n1 = q[1], n2 = q[-ZS - 1], n3 = q[-ZS], n4 = q[-ZS + 1], n5 = q[ZS - 1], n6 = q[ZS], n7 = q[ZS + 1];
+                const uint32_t nm = max(max(max(n0, n1), max(n2, n3)), max(max(n4, n5), max(n6, n7)));
+                ismax = s > nm;      // s > nm >= 0 implies s > 0
             }
             const unsigned long long mm = __builtin_amdgcn_ballot_w64(ismax);
             if (lane == 0) S.masks[it] = mm;
