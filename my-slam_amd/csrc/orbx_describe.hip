@@ -233,11 +233,20 @@ __global__ __launch_bounds__(256) void k_describe(
     DescLds &S = lds[wave];
     ORBX_TRACE_DECL;
 
-    int total = 0, l = -1, idx = 0;
-    for (int i = 0; i < plan.nlevels; i++) {
-        const int c = (int)wk.nk[f * plan.nlevels + i];
-        if (l < 0 && g < total + c) { l = i; idx = g - total; }
-        total += c;
+    // which level's list holds keypoint g of this frame: lane i loads level i's count (one memory round trip, not
+    // nlevels dependent scalar loads), an inclusive scan over the first 16 lanes (DPP row shifts), a ballot
+    int total, l, idx;
+    {
+        const int nl = plan.nlevels;                                            // <= ORBX_MAX_LEVELS = 16: one DPP row
+        int incl = lane < nl ? (int)wk.nk[f * nl + lane] : 0;
+        incl += __builtin_amdgcn_update_dpp(0, incl, 0x111, 0xf, 0xf, true);   // row_shr:1, lanes without a source add 0
+        incl += __builtin_amdgcn_update_dpp(0, incl, 0x112, 0xf, 0xf, true);
+        incl += __builtin_amdgcn_update_dpp(0, incl, 0x114, 0xf, 0xf, true);
+        incl += __builtin_amdgcn_update_dpp(0, incl, 0x118, 0xf, 0xf, true);
+        total = __builtin_amdgcn_readlane(incl, nl - 1);
+        l = __popcll(__builtin_amdgcn_ballot_w64(lane < nl && g >= incl));      // levels that end at or before g
+        idx = g - (l > 0 ? __builtin_amdgcn_readlane(incl, l - 1) : 0);
+        if (l >= nl) l = -1;
     }
     if (g == 0 && lane == 0) {
         const uint32_t e = wk.errflags[f];
