@@ -219,7 +219,7 @@ ORBX_TRACE_DEFINE(g_desc_trace, orbx_debug_desc_trace)
 
 __global__ __launch_bounds__(256) void k_describe(
     OrbxPlan plan, OrbxWork wk, orbx_keypoint *__restrict__ kps, uint8_t *__restrict__ desc,
-    int32_t *__restrict__ counts, int32_t *__restrict__ status, int l0_aligned, int wg_per_frame, int nwg)
+    int32_t *__restrict__ counts, int32_t *__restrict__ status, int l0_aligned, int wg_per_frame, int nwg, uint32_t wg_rcp)
 {
     __shared__ DescLds lds[4];
     const int lane = threadIdx.x & 63;
@@ -228,7 +228,9 @@ __global__ __launch_bounds__(256) void k_describe(
     // one frame overlap heavily, and its whole pyramid fits the XCD's L2.  Speed only; the padded grid keeps it a bijection.
     const int lb = (int)(blockIdx.x & 7u) * (int)(gridDim.x >> 3) + (int)(blockIdx.x >> 3);
     if (lb >= nwg) return;
-    const int f = lb / wg_per_frame;
+    // lb / wg_per_frame without the integer-division expansion: multiply by floor(2^32 / d) + 1, one correction step
+    int f = wg_rcp ? (int)__umulhi((uint32_t)lb, wg_rcp) : lb;   // wg_rcp == 0: one workgroup per frame
+    f -= (f * wg_per_frame > lb) ? 1 : 0;
     const int g = (lb - f * wg_per_frame) * 4 + wave;
     DescLds &S = lds[wave];
     ORBX_TRACE_DECL;
@@ -475,5 +477,5 @@ void orbx_launch_describe(const OrbxPlan &plan, const OrbxWork &wk, int nframes,
     const int wg_per_frame = (plan.out_cap + 3) / 4;
     const int nwg = wg_per_frame * nframes;
     hipLaunchKernelGGL(k_describe, dim3((nwg + 7) & ~7), dim3(256), 0, s, plan, wk, d_kps, d_desc, d_counts, d_status, l0_aligned,
-                       wg_per_frame, nwg);
+                       wg_per_frame, nwg, wg_per_frame > 1 ? (uint32_t)((1ull << 32) / (unsigned)wg_per_frame + 1) : 0u);
 }

@@ -150,7 +150,7 @@ ORBX_TRACE_DEFINE(g_fast_trace, orbx_debug_fast_trace)
 
 template <int TS, int TH, int ZS>
 __global__ __launch_bounds__(FAST_THREADS) void k_fast_cells(OrbxPlan plan, OrbxWork wk, int l0_aligned, int cell_lo, int cell_hi,
-                                                             int wg_per_frame, int nwg)
+                                                             int wg_per_frame, int nwg, uint32_t wg_rcp)
 {
     __shared__ __attribute__((aligned(16))) FastLds<TS, TH, ZS> lds[FAST_THREADS / 64];
     const int lane = threadIdx.x & 63;
@@ -160,7 +160,9 @@ __global__ __launch_bounds__(FAST_THREADS) void k_fast_cells(OrbxPlan plan, Orbx
     // The grid is padded to a multiple of 8, which makes the map a bijection.  Placement is for speed only.
     const int lb = (int)(blockIdx.x & 7u) * (int)(gridDim.x >> 3) + (int)(blockIdx.x >> 3);
     if (lb >= nwg) return;
-    const int f = lb / wg_per_frame;
+    // lb / wg_per_frame without the integer-division expansion: multiply by floor(2^32 / d) + 1, one correction step
+    int f = wg_rcp ? (int)__umulhi((uint32_t)lb, wg_rcp) : lb;   // wg_rcp == 0: one workgroup per frame
+    f -= (f * wg_per_frame > lb) ? 1 : 0;
     const int cell = cell_lo + (lb - f * wg_per_frame) * (FAST_THREADS / 64) + wave;
     if (cell >= cell_hi) return;
     FastLds<TS, TH, ZS> &S = lds[wave];
@@ -390,7 +392,7 @@ void orbx_launch_fast(const OrbxPlan &plan, const OrbxWork &wk, int nframes, int
     const int nwg = wg_per_frame * nframes;
     dim3 grid((nwg + 7) & ~7);
     if (maxcell <= 38)   // tile <= 44x44, zone <= 38x38; row = 4 pad + 3 + 44 + over-read -> 56 B
-        hipLaunchKernelGGL((k_fast_cells<56, 44, 40>), grid, dim3(FAST_THREADS), 0, s, plan, wk, l0_aligned, cell_lo, cell_hi, wg_per_frame, nwg);
+        hipLaunchKernelGGL((k_fast_cells<56, 44, 40>), grid, dim3(FAST_THREADS), 0, s, plan, wk, l0_aligned, cell_lo, cell_hi, wg_per_frame, nwg, wg_per_frame > 1 ? (uint32_t)((1ull << 32) / (unsigned)wg_per_frame + 1) : 0u);
     else                 // cells of tiny levels: tile <= 66x66, zone <= 60x60
-        hipLaunchKernelGGL((k_fast_cells<80, 66, 64>), grid, dim3(FAST_THREADS), 0, s, plan, wk, l0_aligned, cell_lo, cell_hi, wg_per_frame, nwg);
+        hipLaunchKernelGGL((k_fast_cells<80, 66, 64>), grid, dim3(FAST_THREADS), 0, s, plan, wk, l0_aligned, cell_lo, cell_hi, wg_per_frame, nwg, wg_per_frame > 1 ? (uint32_t)((1ull << 32) / (unsigned)wg_per_frame + 1) : 0u);
 }
