@@ -197,28 +197,40 @@ __device__ __forceinline__ void oct_body(const OrbxPlan &plan, const OrbxWork &w
                 }                                                       \
             }                                                           \
         }                                                               \
-        _Pragma("unroll") for (int u = 0; u < KU; u++) {                \
-            if (kb + u * T >= n) break;                                 \
-            const int k = kb + u * T + tidv;                            \
-            int ai = -1;      /* counter this key increments, if any */ \
-            if (k < n) {
+        /* Four keys at a time.  The body is straight-line code (predicated by `valid`, LDS reads at clamped indices), so \
+           the dependent LDS look-ups of the four keys overlap instead of running one key after the other. */           \
+        _Pragma("unroll") for (int u0 = 0; u0 < KU; u0 += 4) {          \
+            if (kb + u0 * T >= n) break;                                \
+            int aiv[4];                                                 \
+            _Pragma("unroll") for (int j = 0; j < 4; j++) {             \
+                const int u = u0 + j;                                   \
+                const int k = kb + u * T + tidv;                        \
+                const bool valid = k < n;                               \
+                int ai = -1;      /* counter this key increments, if any */ \
+                {
 #define SETOWN(v)                                                       \
     do {                                                                \
-        wv[u] = (v);                                                    \
-        if (!REG) owner[k] = wv[u];                                     \
+        const uint32_t nv_ = (v);                                       \
+        if (!REG && valid && nv_ != wv[u]) owner[k] = nv_;              \
+        wv[u] = nv_;                                                    \
     } while (0)
 #define KEYLOOP_END_COUNT(ctr)                                          \
+                }                                                       \
+                aiv[j] = ai;                                            \
             }                                                           \
-            wave_count(ctr, ai);                                        \
-            if ((u & 3) == 3) __builtin_amdgcn_sched_barrier(0);   /* keep the live ranges of 4 keys, not of all KU */ \
+            _Pragma("unroll") for (int j = 0; j < 4; j++) wave_count(ctr, aiv[j]);   \
+            __builtin_amdgcn_sched_barrier(0);   /* keep the live ranges of 4 keys, not of all KU */ \
         }                                                               \
     }
 #define KEYLOOP_END                                                     \
+                }                                                       \
+                aiv[j] = ai;                                            \
             }                                                           \
-            (void)ai;                                                   \
-            if ((u & 3) == 3) __builtin_amdgcn_sched_barrier(0);        \
+            (void)aiv;                                                  \
+            __builtin_amdgcn_sched_barrier(0);                          \
         }                                                               \
     }
+    static_assert(KU % 4 == 0, "keys are processed four at a time");
     const int tid = threadIdx.x;
 #ifdef OCT_TRACE
     int tp = 0;
@@ -243,8 +255,9 @@ __device__ __forceinline__ void oct_body(const OrbxPlan &plan, const OrbxWork &w
         const int xr = (int)(xyv[u] & 0xFFFFu) - ORBX_MINB;
         int b = (int)__fdiv_rn((float)xr, L.hX);
         b = min(max(b, 0), nIni - 1);
-        SETOWN((uint32_t)b);
-        ai = b;
+        if (!REG && valid) owner[k] = (uint32_t)b;
+        wv[u] = (uint32_t)b;
+        ai = valid ? b : -1;
     KEYLOOP_END_COUNT(cc)
     __syncthreads();
     for (int i = tid; i < nIni; i += T) {
@@ -275,12 +288,11 @@ __device__ __forceinline__ void oct_body(const OrbxPlan &plan, const OrbxWork &w
     __syncthreads();
     KEYLOOP_BEGIN(true, true)
         const uint32_t id = wv[u];
-        const OrbxNode nd = lnA[id];
-        if (nd.count > 1) {
-            const uint32_t q = oct_quadrant(nd, xyv[u]);
-            ai = 4 * nd.slot + (int)q;
-            SETOWN(id | (q << 30));
-        }
+        const OrbxNode nd = lnA[valid ? id : 0u];
+        const bool alive = valid && nd.count > 1;
+        const uint32_t q = oct_quadrant(nd, xyv[u]);
+        ai = alive ? 4 * nd.slot + (int)q : -1;
+        SETOWN(alive ? (id | (q << 30)) : id);
     KEYLOOP_END_COUNT(cc)
     __syncthreads();
 
@@ -372,10 +384,12 @@ __device__ __forceinline__ void oct_body(const OrbxPlan &plan, const OrbxWork &w
             KEYLOOP_BEGIN(true, false)
                 const uint32_t w = wv[u];
                 const uint32_t id = w & OCT_ID_MASK;
-                if ((int)id >= lastBase) {
-                    const OrbxNode nd = lnA[id - lastBase];
-                    if (nd.count > 1) SETOWN(nd.slot < nE ? cc[4 * nd.slot + (w >> 30)] : id);
-                }
+                const bool inwin = valid && (int)id >= lastBase;
+                const OrbxNode nd = lnA[inwin ? id - lastBase : 0u];
+                const bool alive = inwin && nd.count > 1;
+                const bool expd = alive && nd.slot < nE;
+                const uint32_t child = cc[expd ? 4 * nd.slot + (w >> 30) : 0u];
+                SETOWN(alive ? (expd ? child : id) : w);
             KEYLOOP_END
             m = newM;
             { uint32_t *t2 = cur; cur = nxt; nxt = t2; }
@@ -390,20 +404,15 @@ __device__ __forceinline__ void oct_body(const OrbxPlan &plan, const OrbxWork &w
         KEYLOOP_BEGIN(true, true)
             const uint32_t w = wv[u];
             const uint32_t id = w & OCT_ID_MASK;
-            if ((int)id >= lastBase) {
-                const OrbxNode nd = lnA[id - lastBase];
-                if (nd.count > 1) {
-                    const uint32_t child = cc[4 * nd.slot + (w >> 30)];
-                    const OrbxNode ch = lnB[child - arenaN];
-                    if (ch.count > 1) {
-                        const uint32_t q = oct_quadrant(ch, xyv[u]);
-                        ai = 4 * ch.slot + (int)q;
-                        SETOWN(child | (q << 30));
-                    } else {
-                        SETOWN(child);
-                    }
-                }
-            }
+            const bool inwin = valid && (int)id >= lastBase;
+            const OrbxNode nd = lnA[inwin ? id - lastBase : 0u];
+            const bool expd = inwin && nd.count > 1;                      // every splittable node is expanded here
+            const uint32_t child = cc[expd ? 4 * nd.slot + (w >> 30) : 0u];
+            const OrbxNode ch = lnB[expd ? child - (uint32_t)arenaN : 0u];
+            const bool deep = expd && ch.count > 1;
+            const uint32_t q = oct_quadrant(ch, xyv[u]);
+            ai = deep ? 4 * ch.slot + (int)q : -1;
+            SETOWN(expd ? (deep ? (child | (q << 30)) : child) : w);
         KEYLOOP_END_COUNT(cn)
         __syncthreads();
         OCT_T(7);
