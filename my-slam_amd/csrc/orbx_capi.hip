@@ -277,6 +277,7 @@ extern "C" int orbx_create(orbx_extractor **out, int nfeatures, float scale_fact
     for (auto &e : h->ev_join) if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) { free_all(h); return fail(ORBX_E_HIP, "hipEventCreate failed"); }
     if (hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming) != hipSuccess) { free_all(h); return fail(ORBX_E_HIP, "hipEventCreate failed"); }
     if (orbx_upload_constants(h->umax, h->gauss_k) != 0) { free_all(h); return fail(ORBX_E_HIP, "constant upload failed"); }
+    if (orbx_selftest_fp16() != 0) { free_all(h); return fail(ORBX_E_HIP, "fp16 subnormal self-test failed: the FAST score tree needs fp16 subnormals enabled on this device"); }
     *out = h;
     return ORBX_OK;
 }

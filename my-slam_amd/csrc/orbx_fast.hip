@@ -379,6 +379,39 @@ __global__ __launch_bounds__(FAST_THREADS) void k_fast_cells(OrbxPlan plan, Orbx
     FT_FLUSH;
 }
 
+// The stage-2 score tree treats bytes as fp16 subnormals: this needs the kernels to run with fp16 subnormals enabled
+// (the compiler's default, .amdhsa_float_denorm_mode_16_64 3).  Checked once per handle at create time, on the device:
+// differences, three-input min/max and the integer read-back of a handful of byte pairs must be exact.
+__global__ void k_fp16_probe(uint32_t *out)
+{
+    const uint32_t a = 200u + threadIdx.x, b = 3u, c = 255u, z = 0u;
+    const hh2 d0 = pkh(a & 255u, b) - pkh(b, a & 255u);     // (a-b, b-a)
+    const hh2 d1 = pkh(c, z) - pkh(z, c);                   // (255, -255)
+    const hh2 d2 = pkh(b, b) - pkh(b, b);                   // (0, 0)
+    const hh2 mn = hmin3(d0, d1, d2), mx = hmax3(d0, d1, d2);
+    const hh2 zero = {(_Float16)0.0f, (_Float16)0.0f};
+    out[2 * threadIdx.x] = __builtin_bit_cast(uint32_t, hmax3(mn, -mx, zero));
+    out[2 * threadIdx.x + 1] = __builtin_bit_cast(uint32_t, hmax3(mx, -mn, zero));
+}
+int orbx_selftest_fp16(void)
+{
+    uint32_t *d = nullptr, h[16];
+    if (hipMalloc((void **)&d, sizeof(h)) != hipSuccess) return -1;
+    hipLaunchKernelGGL(k_fp16_probe, dim3(1), dim3(8), 0, 0, d);
+    const bool ok = hipMemcpy(h, d, sizeof(h), hipMemcpyDeviceToHost) == hipSuccess;
+    (void)hipFree(d);
+    if (!ok) return -1;
+    for (int t = 0; t < 8; t++) {
+        const int a = (200 + t) & 255, b = 3;
+        // lo halves: min3(a-b, 255, 0) = 0, max3 = 255; hi halves: min3(b-a, -255, 0) = -255, max3(b-a, -255, 0) = 0
+        // out0 = max3(mn, -mx, 0)   = (max(0, -255, 0), max(-255, 0, 0))   = (0, 0)
+        // out1 = max3(mx, -mn, 0)   = (max(255, 0, 0), max(0, 255, 0))     = (255, 255)
+        (void)a; (void)b;
+        if (h[2 * t] != 0u || h[2 * t + 1] != (255u | (255u << 16))) return 1;
+    }
+    return 0;
+}
+
 void orbx_launch_fast(const OrbxPlan &plan, const OrbxWork &wk, int nframes, int cell_lo, int cell_hi, hipStream_t s)
 {
     cell_hi = min(cell_hi, plan.ncells);

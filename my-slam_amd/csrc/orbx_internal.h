@@ -128,3 +128,4 @@ void orbx_launch_describe(const OrbxPlan &plan, const OrbxWork &wk, int nframes,
                           int32_t *d_status, hipStream_t s);
 size_t orbx_octree_lds_bytes(int list_cap_max);
 int orbx_upload_constants(const int umax[16], const int gauss_k[7]);
+int orbx_selftest_fp16(void);   // 0 = fp16 subnormal arithmetic behaves as k_fast_cells needs
