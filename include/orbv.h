@@ -13,8 +13,9 @@
  * (src/ORBmatcher.cc:159-288: merge-join of two FeatureVectors, then the best/second-best loop = orbm_best2 /
  * orbm_distances on the CSR lists of orbv_feature_vector) and KeyFrameDatabase (score).
  *
- * The tree descent runs on the GPU (one thread per descriptor); the two tiny ordered maps are assembled on the
- * host exactly as DBoW2 does (same insertion order, double arithmetic).  Deviation where the reference is
+ * The tree descent runs on the GPU (one wave per descriptor, one child per lane); the two tiny ordered maps are
+ * assembled on the host with DBoW2's contents and order (features sorted by (id, feature index), the same double
+ * additions in the same order).  Deviation where the reference is
  * undefined: a trailing empty line of the text file makes loadFromTextFile append a node with an uninitialised
  * descriptor under the root; this loader ignores empty lines.
  */

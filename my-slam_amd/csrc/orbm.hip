@@ -163,6 +163,18 @@ __global__ __launch_bounds__(M_THREADS) void k_dist_csr(
     dist[c] = hamming256(Q[0], Q[1], Tj[0], Tj[1]);
 }
 
+// pairs given explicitly as (query << 16 | train), both below 65536: no per-thread binary search over off[]
+__global__ __launch_bounds__(M_THREADS) void k_dist_pairs16(const uint8_t *__restrict__ q, const uint8_t *__restrict__ t,
+                                                            const uint32_t *__restrict__ pairs, int total, int32_t *__restrict__ dist)
+{
+    const int c = blockIdx.x * M_THREADS + threadIdx.x;
+    if (c >= total) return;
+    const uint32_t p = pairs[c];
+    const uint4 *Q = reinterpret_cast<const uint4 *>(q) + 2 * (long long)(p >> 16);
+    const uint4 *Tj = reinterpret_cast<const uint4 *>(t) + 2 * (long long)(p & 0xFFFFu);
+    dist[c] = hamming256(Q[0], Q[1], Tj[0], Tj[1]);
+}
+
 __global__ __launch_bounds__(M_THREADS) void k_dist_dense(
     const uint8_t *__restrict__ q, int nq, const uint8_t *__restrict__ t, int nt, int32_t *__restrict__ dist)
 {
@@ -319,6 +331,7 @@ extern "C" void orbm_destroy(orbm_matcher *m)
     (void)hipFree(m->grid.kx); (void)hipFree(m->grid.ky); (void)hipFree(m->grid.koct); (void)hipFree(m->grid.cell_start);
     (void)hipFree(m->grid.items); (void)hipFree(m->grid.cell_of); (void)hipFree(m->d_qf); (void)hipFree(m->d_qi); (void)hipFree(m->d_skip);
     if (m->stream) (void)hipStreamDestroy(m->stream);
+    (void)hipHostFree(m->h_pin);
     delete m;
 }
 
@@ -561,28 +574,50 @@ extern "C" int orbm_search_by_bow(orbm_matcher *m,
     if (nq == 0 || pairs == 0) return ORBX_OK;
     if (nq > m->max_q) return mfail(ORBX_E_CAPACITY, "%d key-frame features to match, matcher sized for %d queries", nq, m->max_q);
     if (pairs > m->max_pairs) return mfail(ORBX_E_CAPACITY, "%lld candidate pairs, matcher sized for %d", pairs, m->max_pairs);
-    std::vector<int32_t> idx((size_t)pairs), dist((size_t)pairs);
+    // pinned staging block: [nq x 32 query descriptors | n_f x 32 frame descriptors | nq+1 offsets | pairs indices | pairs distances]
+    MHIPCHK(hipSetDevice(m->device));
+    hipStream_t s = m->stream;
+    const size_t o_q = 0, o_t = o_q + (size_t)nq * 32, o_off = o_t + (size_t)n_f * 32, o_idx = o_off + ((size_t)nq + 1) * 4;
+    const size_t o_dist = o_idx + (size_t)pairs * 4, need = o_dist + (size_t)pairs * 4;
+    if (need > m->h_pin_bytes) {
+        MHIPCHK(hipStreamSynchronize(s));
+        (void)hipHostFree(m->h_pin); m->h_pin = nullptr; m->h_pin_bytes = 0;
+        MHIPCHK(hipHostMalloc((void **)&m->h_pin, need + need / 2, hipHostMallocDefault));
+        m->h_pin_bytes = need + need / 2;
+    }
+    memcpy(m->h_pin + o_q, qdesc.data(), (size_t)nq * 32);
+    memcpy(m->h_pin + o_t, desc_f, (size_t)n_f * 32);
+    memcpy(m->h_pin + o_off, off.data(), ((size_t)nq + 1) * 4);
+    int32_t *idx = reinterpret_cast<int32_t *>(m->h_pin + o_idx);
+    const int32_t *dist = reinterpret_cast<const int32_t *>(m->h_pin + o_dist);
     for (int i = 0; i < nq; i++) {
         const int b = qs[i].f_node;
-        int32_t *dst = idx.data() + off[i];
+        int32_t *dst = idx + off[i];
         for (int c = fv_f_off[b]; c < fv_f_off[b + 1]; c++) {
             const int fi = fv_f_idx[c];
             if (fi < 0 || fi >= n_f) return mfail(ORBX_E_INVALID, "frame feature index %d outside [0,%d)", fi, n_f);
             *dst++ = fi;
         }
     }
-    MHIPCHK(hipSetDevice(m->device));
-    hipStream_t s = m->stream;
-    MHIPCHK(hipMemcpyAsync(m->d_q, qdesc.data(), (size_t)nq * 32, hipMemcpyHostToDevice, s));
-    MHIPCHK(hipMemcpyAsync(m->d_t, desc_f, (size_t)n_f * 32, hipMemcpyHostToDevice, s));
-    MHIPCHK(hipMemcpyAsync(m->d_off, off.data(), ((size_t)nq + 1) * 4, hipMemcpyHostToDevice, s));
-    MHIPCHK(hipMemcpyAsync(m->d_idx, idx.data(), (size_t)pairs * 4, hipMemcpyHostToDevice, s));
-    hipLaunchKernelGGL(k_dist_csr, dim3((unsigned)((pairs + M_THREADS - 1) / M_THREADS)), dim3(M_THREADS), 0, s,
-                       m->d_q, nq, m->d_t, m->d_off, m->d_idx, (int)pairs, m->d_out);
+    MHIPCHK(hipMemcpyAsync(m->d_q, m->h_pin + o_q, (size_t)nq * 32, hipMemcpyHostToDevice, s));
+    MHIPCHK(hipMemcpyAsync(m->d_t, m->h_pin + o_t, (size_t)n_f * 32, hipMemcpyHostToDevice, s));
+    if (nq < 65536 && n_f < 65536) {   // the usual case: ship (query << 16 | train) per pair
+        for (int i = 0; i < nq; i++)
+            for (int c = off[i]; c < off[i + 1]; c++) idx[c] |= (int32_t)((uint32_t)i << 16);
+        MHIPCHK(hipMemcpyAsync(m->d_idx, m->h_pin + o_idx, (size_t)pairs * 4, hipMemcpyHostToDevice, s));
+        hipLaunchKernelGGL(k_dist_pairs16, dim3((unsigned)((pairs + M_THREADS - 1) / M_THREADS)), dim3(M_THREADS), 0, s,
+                           m->d_q, m->d_t, reinterpret_cast<const uint32_t *>(m->d_idx), (int)pairs, m->d_out);
+    } else {
+        MHIPCHK(hipMemcpyAsync(m->d_off, m->h_pin + o_off, ((size_t)nq + 1) * 4, hipMemcpyHostToDevice, s));
+        MHIPCHK(hipMemcpyAsync(m->d_idx, m->h_pin + o_idx, (size_t)pairs * 4, hipMemcpyHostToDevice, s));
+        hipLaunchKernelGGL(k_dist_csr, dim3((unsigned)((pairs + M_THREADS - 1) / M_THREADS)), dim3(M_THREADS), 0, s,
+                           m->d_q, nq, m->d_t, m->d_off, m->d_idx, (int)pairs, m->d_out);
+    }
     MHIPCHK(hipGetLastError());
-    MHIPCHK(hipMemcpyAsync(dist.data(), m->d_out, (size_t)pairs * 4, hipMemcpyDeviceToHost, s));
+    MHIPCHK(hipMemcpyAsync(m->h_pin + o_dist, m->d_out, (size_t)pairs * 4, hipMemcpyDeviceToHost, s));
     MHIPCHK(hipStreamSynchronize(s));
     // sequential selection (:199-246)
+    const bool packed16 = nq < 65536 && n_f < 65536;
     int32_t hist[ORBM_HISTO_LENGTH] = {0};
     std::vector<int> bin_of((size_t)n_f, -1);
     const float factor = 1.0f / ORBM_HISTO_LENGTH;
@@ -590,7 +625,7 @@ extern "C" int orbm_search_by_bow(orbm_matcher *m,
     for (int i = 0; i < nq; i++) {
         int best1 = 256, best2 = 256, bestF = -1;
         for (int c = off[i]; c < off[i + 1]; c++) {
-            const int fi = idx[c];
+            const int fi = packed16 ? (int)((uint32_t)idx[c] & 0xFFFFu) : idx[c];
             if (match_f[fi] >= 0) continue;                 // :209
             const int d = dist[c];
             if (d < best1) { best2 = best1; best1 = d; bestF = fi; }

@@ -50,5 +50,6 @@ struct orbm_matcher {
     OrbmGrid grid = {};  bool grid_ok = false;                       // N1: Frame grid of the last orbm_grid_build
     float *d_qf = nullptr; int32_t *d_qi = nullptr; uint8_t *d_skip = nullptr;   // window-query staging (lazy)
     size_t qf_elems = 0;
+    uint8_t *h_pin = nullptr; size_t h_pin_bytes = 0;   // pinned staging of orbm_search_by_bow (lazy)
 };
 

@@ -1,6 +1,8 @@
 // orbv.hip -- DBoW2 vocabulary tree: text loader, GPU descent, BowVector / FeatureVector.
 // Reference: Thirdparty/DBoW2/DBoW2/TemplatedVocabulary.h:1127-1259,1338-1424, BowVector.cpp, FeatureVector.cpp,
 // ScoringObject.cpp, FORB.cpp of WChen09/My-SLAM.  See include/orbv.h.
+#include <cstring>
+#include <algorithm>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -43,38 +45,50 @@ struct orbv_vocabulary {
     double *d_weight = nullptr;
     // staging
     uint8_t *d_feat = nullptr; int32_t *d_out_i = nullptr; double *d_out_w = nullptr; size_t cap_feat = 0;
+    hipStream_t stream = nullptr;
+    uint8_t *h_pin = nullptr;      // pinned: [cap_feat * 32] features in, [cap_feat * 16] results out
 };
 
-// greedy descent (TemplatedVocabulary.h:1218-1259): one thread per feature
+// greedy descent (TemplatedVocabulary.h:1218-1259): one WAVE per feature.  At every node the lanes take one child each
+// (all k descriptors are fetched in one memory round trip instead of k dependent ones), the wave's minimum of
+// distance << 16 | child position picks the closest child, the first one on ties (strict '<' at :1246).
 __global__ __launch_bounds__(256) void k_voc_transform(const int32_t *__restrict__ child_off, const int32_t *__restrict__ child_ids,
                                                       const uint8_t *__restrict__ ndesc, const int32_t *__restrict__ word_of,
                                                       const double *__restrict__ nweight, const uint8_t *__restrict__ feat, int n,
                                                       int nid_level, int32_t *__restrict__ word_id, int32_t *__restrict__ node_id,
                                                       double *__restrict__ weight)
 {
-    const int i = blockIdx.x * 256 + threadIdx.x;
+    const int lane = threadIdx.x & 63;
+    const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (i >= n) return;
     const uint4 *F = reinterpret_cast<const uint4 *>(feat) + 2 * (long long)i;
     const uint4 f0 = F[0], f1 = F[1];
     int final_id = 0, level = 0, nid = 0;
-    do {
+    int c0 = child_off[0], c1 = child_off[1];
+    while (c1 > c0) {                                   // !isLeaf()
         ++level;
-        const int c0 = child_off[final_id], c1 = child_off[final_id + 1];
-        int best = 0x7FFFFFFF, bid = child_ids[c0];
-        for (int c = c0; c < c1; c++) {
-            const int id = child_ids[c];
-            const uint4 *D = reinterpret_cast<const uint4 *>(ndesc) + 2 * (long long)id;
-            const uint4 a0 = D[0], a1 = D[1];
-            const int d = __popc(f0.x ^ a0.x) + __popc(f0.y ^ a0.y) + __popc(f0.z ^ a0.z) + __popc(f0.w ^ a0.w) +
-                          __popc(f1.x ^ a1.x) + __popc(f1.y ^ a1.y) + __popc(f1.z ^ a1.z) + __popc(f1.w ^ a1.w);
-            if (d < best) { best = d; bid = id; }       // strict '<': the first child wins a tie
+        uint32_t best = 0xFFFFFFFFu;
+        for (int cb = c0; cb < c1; cb += 64) {          // k <= 64 in practice: one trip
+            const int c = cb + lane;
+            if (c < c1) {
+                const uint4 *D = reinterpret_cast<const uint4 *>(ndesc) + 2 * (long long)child_ids[c];
+                const uint4 a0 = D[0], a1 = D[1];
+                const uint32_t d = __popc(f0.x ^ a0.x) + __popc(f0.y ^ a0.y) + __popc(f0.z ^ a0.z) + __popc(f0.w ^ a0.w) +
+                                   __popc(f1.x ^ a1.x) + __popc(f1.y ^ a1.y) + __popc(f1.z ^ a1.z) + __popc(f1.w ^ a1.w);
+                best = min(best, (d << 16) | (uint32_t)min(c - c0, 0xFFFF));
+            }
         }
-        final_id = bid;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) best = min(best, (uint32_t)__shfl_xor((int)best, o));
+        final_id = child_ids[c0 + (int)(best & 0xFFFFu)];
         if (level == nid_level) nid = final_id;
-    } while (child_off[final_id + 1] > child_off[final_id]);   // !isLeaf()
-    word_id[i] = word_of[final_id];
-    node_id[i] = nid;
-    weight[i] = nweight[final_id];
+        c0 = child_off[final_id]; c1 = child_off[final_id + 1];
+    }
+    if (lane == 0) {
+        word_id[i] = word_of[final_id];
+        node_id[i] = nid;
+        weight[i] = nweight[final_id];
+    }
 }
 
 extern "C" void orbv_destroy(orbv_vocabulary *v)
@@ -83,6 +97,8 @@ extern "C" void orbv_destroy(orbv_vocabulary *v)
     (void)hipSetDevice(v->device);
     (void)hipFree(v->d_child_off); (void)hipFree(v->d_child_ids); (void)hipFree(v->d_word_of); (void)hipFree(v->d_desc);
     (void)hipFree(v->d_weight); (void)hipFree(v->d_feat); (void)hipFree(v->d_out_i); (void)hipFree(v->d_out_w);
+    (void)hipHostFree(v->h_pin);
+    if (v->stream) (void)hipStreamDestroy(v->stream);
     delete v;
 }
 
@@ -165,22 +181,33 @@ extern "C" int orbv_transform_features(orbv_vocabulary *v, const uint8_t *desc, 
     if (n == 0) return ORBX_OK;
     if (!desc || !word_id || !node_id || !weight) return vfail(ORBX_E_INVALID, "NULL buffer");
     VHIP(hipSetDevice(v->device));
+    if (!v->stream) VHIP(hipStreamCreateWithFlags(&v->stream, hipStreamNonBlocking));
     if ((size_t)n > v->cap_feat) {
-        (void)hipFree(v->d_feat); (void)hipFree(v->d_out_i); (void)hipFree(v->d_out_w);
-        v->d_feat = nullptr; v->d_out_i = nullptr; v->d_out_w = nullptr; v->cap_feat = 0;
-        VHIP(hipMalloc((void **)&v->d_feat, (size_t)n * 32));
-        VHIP(hipMalloc((void **)&v->d_out_i, (size_t)n * 8));
-        VHIP(hipMalloc((void **)&v->d_out_w, (size_t)n * 8));
-        v->cap_feat = (size_t)n;
+        VHIP(hipStreamSynchronize(v->stream));
+        (void)hipFree(v->d_feat); (void)hipFree(v->d_out_i); (void)hipFree(v->d_out_w); (void)hipHostFree(v->h_pin);
+        v->d_feat = nullptr; v->d_out_i = nullptr; v->d_out_w = nullptr; v->h_pin = nullptr; v->cap_feat = 0;
+        const size_t cap = (size_t)n + (size_t)n / 4 + 64;
+        VHIP(hipMalloc((void **)&v->d_feat, cap * 32));
+        VHIP(hipMalloc((void **)&v->d_out_i, cap * 16));      // [cap] word | [cap] node | [cap] weight (double): one block, one copy back
+        VHIP(hipHostMalloc((void **)&v->h_pin, cap * 48, hipHostMallocDefault));
+        v->cap_feat = cap;
     }
-    VHIP(hipMemcpy(v->d_feat, desc, (size_t)n * 32, hipMemcpyHostToDevice));
+    // pinned staging + one stream: one copy in, one kernel, one copy out, one synchronisation
+    const size_t cap = v->cap_feat;
+    std::memcpy(v->h_pin, desc, (size_t)n * 32);
+    VHIP(hipMemcpyAsync(v->d_feat, v->h_pin, (size_t)n * 32, hipMemcpyHostToDevice, v->stream));
     const int nid_level = v->L - levelsup;      // <= 0: nid stays 0 (the root), :1228-1229
-    hipLaunchKernelGGL(k_voc_transform, dim3((n + 255) / 256), dim3(256), 0, 0, v->d_child_off, v->d_child_ids, v->d_desc, v->d_word_of,
-                       v->d_weight, v->d_feat, n, nid_level, v->d_out_i, v->d_out_i + n, v->d_out_w);
+    int32_t *d_word = v->d_out_i, *d_node = v->d_out_i + cap;
+    double *d_w = reinterpret_cast<double *>(v->d_out_i + 2 * cap);
+    hipLaunchKernelGGL(k_voc_transform, dim3((n + 3) / 4), dim3(256), 0, v->stream, v->d_child_off, v->d_child_ids, v->d_desc, v->d_word_of,
+                       v->d_weight, v->d_feat, n, nid_level, d_word, d_node, d_w);
     VHIP(hipGetLastError());
-    VHIP(hipMemcpy(word_id, v->d_out_i, (size_t)n * 4, hipMemcpyDeviceToHost));
-    VHIP(hipMemcpy(node_id, v->d_out_i + n, (size_t)n * 4, hipMemcpyDeviceToHost));
-    VHIP(hipMemcpy(weight, v->d_out_w, (size_t)n * 8, hipMemcpyDeviceToHost));
+    uint8_t *h_out = v->h_pin + cap * 32;
+    VHIP(hipMemcpyAsync(h_out, v->d_out_i, cap * 16, hipMemcpyDeviceToHost, v->stream));
+    VHIP(hipStreamSynchronize(v->stream));
+    std::memcpy(word_id, h_out, (size_t)n * 4);
+    std::memcpy(node_id, h_out + cap * 4, (size_t)n * 4);
+    std::memcpy(weight, h_out + cap * 8, (size_t)n * 8);
     return ORBX_OK;
 }
 
@@ -191,28 +218,39 @@ extern "C" int orbv_bow_vector(const orbv_vocabulary *v, const int32_t *word_id,
     if (!v || n < 0 || (n > 0 && (!word_id || !weight))) return vfail(ORBX_E_INVALID, "bad argument");
     const bool must = v->scoring != ORBV_DOT_PRODUCT;                  // ScoringObject.h:74-89
     const bool l2 = v->scoring == ORBV_L2_NORM;
-    std::map<int32_t, double> bow;
-    if (v->weighting == ORBV_TF || v->weighting == ORBV_TF_IDF) {
-        for (int i = 0; i < n; i++)
-            if (weight[i] > 0) bow[word_id[i]] += weight[i];           // addWeight
-        if (!bow.empty() && !must) {
-            const double nd = (double)bow.size();
-            for (auto &kv : bow) kv.second /= nd;
-        }
-    } else {
-        for (int i = 0; i < n; i++)
-            if (weight[i] > 0) bow.insert(std::make_pair(word_id[i], weight[i]));   // addIfNotExist
+    // The reference's std::map<WordId, WordValue> filled in feature order == features sorted by (word id, feature index)
+    // and folded per word in that order (the same floating-point additions in the same order), without a tree node
+    // allocation per word.
+    std::vector<unsigned long long> key;
+    key.reserve((size_t)n);
+    for (int i = 0; i < n; i++)
+        if (weight[i] > 0) key.push_back(((unsigned long long)(uint32_t)word_id[i] << 32) | (uint32_t)i);
+    std::sort(key.begin(), key.end());
+    std::vector<int32_t> bid; std::vector<double> bval;
+    bid.reserve(key.size()); bval.reserve(key.size());
+    const bool tf = v->weighting == ORBV_TF || v->weighting == ORBV_TF_IDF;
+    for (size_t a = 0; a < key.size();) {
+        const int32_t w = (int32_t)(key[a] >> 32);
+        double acc = weight[(uint32_t)key[a]];                         // first occurrence: insert (addWeight / addIfNotExist)
+        size_t b = a + 1;
+        for (; b < key.size() && (int32_t)(key[b] >> 32) == w; b++)
+            if (tf) acc += weight[(uint32_t)key[b]];                   // addWeight: += in feature order; addIfNotExist keeps the first
+        bid.push_back(w); bval.push_back(acc);
+        a = b;
+    }
+    if (tf && !bid.empty() && !must) {
+        const double nd = (double)bid.size();
+        for (double &x : bval) x /= nd;
     }
     if (must) {                                                        // BowVector::normalize
         double norm = 0.0;
-        if (!l2) for (auto &kv : bow) norm += fabs(kv.second);
-        else { for (auto &kv : bow) norm += kv.second * kv.second; norm = sqrt(norm); }
-        if (norm > 0.0) for (auto &kv : bow) kv.second /= norm;
+        if (!l2) for (double x : bval) norm += fabs(x);
+        else { for (double x : bval) norm += x * x; norm = sqrt(norm); }
+        if (norm > 0.0) for (double &x : bval) x /= norm;
     }
-    if ((int)bow.size() > cap) return vfail(ORBX_E_CAPACITY, "%zu words, capacity %d", bow.size(), cap);
-    int o = 0;
-    for (auto &kv : bow) { ids[o] = kv.first; vals[o] = kv.second; o++; }
-    return o;
+    if ((int)bid.size() > cap) return vfail(ORBX_E_CAPACITY, "%zu words, capacity %d", bid.size(), cap);
+    for (size_t o = 0; o < bid.size(); o++) { ids[o] = bid[o]; vals[o] = bval[o]; }
+    return (int)bid.size();
 }
 
 // FeatureVector.cpp:31-45 (features of stopped words are not added, TemplatedVocabulary.h:1157-1161)
@@ -220,16 +258,22 @@ extern "C" int orbv_feature_vector(const int32_t *node_id, const double *weight,
                                    int32_t *node_ids, int32_t *off, int32_t *idx, int cap_nodes)
 {
     if (n < 0 || (n > 0 && (!node_id || !weight)) || !off) return vfail(ORBX_E_INVALID, "bad argument");
-    std::map<int32_t, std::vector<int32_t>> fv;
+    // std::map<NodeId, std::vector<unsigned>> with push_back in feature order == sort by (node id, feature index)
+    std::vector<unsigned long long> key;
+    key.reserve((size_t)n);
     for (int i = 0; i < n; i++)
-        if (weight[i] > 0) fv[node_id[i]].push_back(i);
-    if ((int)fv.size() > cap_nodes) return vfail(ORBX_E_CAPACITY, "%zu nodes, capacity %d", fv.size(), cap_nodes);
-    int o = 0, e = 0;
+        if (weight[i] > 0) key.push_back(((unsigned long long)(uint32_t)node_id[i] << 32) | (uint32_t)i);
+    std::sort(key.begin(), key.end());
+    int o = 0;
     off[0] = 0;
-    for (auto &kv : fv) {
-        node_ids[o] = kv.first;
-        for (int32_t i : kv.second) idx[e++] = i;
-        off[++o] = e;
+    for (size_t a = 0; a < key.size(); a++) {
+        const int32_t nd = (int32_t)(key[a] >> 32);
+        if (a == 0 || nd != (int32_t)(key[a - 1] >> 32)) {
+            if (o >= cap_nodes) return vfail(ORBX_E_CAPACITY, "more than %d nodes", cap_nodes);
+            node_ids[o++] = nd;
+        }
+        idx[a] = (int32_t)(uint32_t)key[a];
+        off[o] = (int32_t)a + 1;
     }
     return o;
 }

@@ -1,0 +1,104 @@
+// track_harness.cc -- BASELINE config 5's per-frame loop without the pose solvers, host side in C++ through the C ABI
+// exactly as INTEGRATION.md wires it into the reference:
+//     Frame::ExtractORB                 -> orbx_extract
+//     Frame::AssignFeaturesToGrid       -> orbm_grid_build
+//     Frame::ComputeBoW                 -> orbv_transform_features + orbv_bow_vector + orbv_feature_vector
+//     Tracking::TrackReferenceKeyFrame  -> orbm_search_by_bow            (ORBmatcher(0.7, true), src/Tracking.cc:774-779)
+//     Tracking::TrackWithMotionModel    -> orbm_search_area_best2 + orbm_rot_filter   (window 15 * scale, octave +-1, TH_HIGH)
+// EPnP RANSAC / g2o pose optimisation (src/PnPsolver.cc, src/Optimizer.cc) are not part of this repository.
+// Inputs: a raw frame file (nframes x H x W bytes) and a vocabulary text file, both written by tools/track/prep_inputs.py.
+// build: g++ -O2 -std=c++17 -I include tools/track/track_harness.cc -L my-slam_amd/lib -lorbx -Wl,-rpath,$PWD/my-slam_amd/lib -o tools/track/track_harness
+#include <algorithm>
+#include <chrono>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+#include "orbx.h"
+#include "orbm.h"
+#include "orbv.h"
+
+static double now_ms() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+#define CHK(e) do { int rc_ = (e); if (rc_ < 0) { fprintf(stderr, "%s failed: %d (%s | %s | %s)\n", #e, rc_, orbx_last_error(), orbm_last_error(), orbv_last_error()); return 2; } } while (0)
+
+struct FrameData {
+    std::vector<orbx_keypoint> kps;
+    std::vector<uint8_t> desc;
+    int n = 0;
+    std::vector<int32_t> fv_node, fv_off, fv_idx; int fv_n = 0;
+};
+
+int main(int argc, char **argv)
+{
+    if (argc < 7) { fprintf(stderr, "usage: %s frames.raw W H nframes voc.txt nfeatures [levelsup]\n", argv[0]); return 1; }
+    const char *fpath = argv[1]; const int W = atoi(argv[2]), H = atoi(argv[3]), K = atoi(argv[4]);
+    const char *vpath = argv[5]; const int NF = atoi(argv[6]); const int levelsup = argc > 7 ? atoi(argv[7]) : 2;
+    std::vector<uint8_t> frames((size_t)W * H * K);
+    FILE *f = fopen(fpath, "rb");
+    if (!f || fread(frames.data(), 1, frames.size(), f) != frames.size()) { fprintf(stderr, "cannot read %s\n", fpath); return 1; }
+    fclose(f);
+
+    orbx_extractor *ex = nullptr; orbm_matcher *mt = nullptr; orbv_vocabulary *voc = nullptr;
+    CHK(orbx_create(&ex, NF, 1.2f, 8, 20, 7, 0, W, H, 1));
+    const int cap = orbx_capacity(ex);
+    CHK(orbm_create(&mt, 0, cap, cap, 1 << 21));
+    CHK(orbv_load_text(&voc, vpath, 0));
+
+    FrameData cur, prev;
+    std::vector<int32_t> word(cap), node(cap), bow_ids(cap), match_f(cap), bi(cap), bd(cap), sd(cap), m12(cap), mn(cap), mx(cap);
+    std::vector<double> weight(cap), bow_vals(cap);
+    std::vector<float> qx(cap), qy(cap), qr(cap), aq(cap), at(cap);
+    double t_stage[5] = {0, 0, 0, 0, 0};
+    std::vector<double> t_all;
+    long nm_bow = 0, nm_proj = 0;
+    for (int k = 0; k < K; k++) {
+        cur.kps.resize(cap); cur.desc.resize((size_t)cap * 32);
+        cur.fv_node.resize(cap); cur.fv_off.resize(cap + 1); cur.fv_idx.resize(cap);
+        const double t0 = now_ms();
+        CHK(orbx_extract(ex, frames.data() + (size_t)k * W * H, W, H, W, cur.kps.data(), cur.desc.data(), cap, &cur.n));
+        const double t1 = now_ms();
+        CHK(orbm_grid_build(mt, cur.kps.data(), cur.n, 0.f, (float)W, 0.f, (float)H));
+        const double t2 = now_ms();
+        CHK(orbv_transform_features(voc, cur.desc.data(), cur.n, levelsup, word.data(), node.data(), weight.data()));
+        const int nb = orbv_bow_vector(voc, word.data(), weight.data(), cur.n, bow_ids.data(), bow_vals.data(), cap);
+        cur.fv_n = orbv_feature_vector(node.data(), weight.data(), cur.n, cur.fv_node.data(), cur.fv_off.data(), cur.fv_idx.data(), cap);
+        if (nb < 0 || cur.fv_n < 0) { fprintf(stderr, "bow failed: %s\n", orbv_last_error()); return 2; }
+        const double t3 = now_ms();
+        if (k > 0) {
+            int nm = 0;      // previous frame in the role of the reference key frame: every feature has a MapPoint
+            CHK(orbm_search_by_bow(mt, prev.desc.data(), prev.kps.data(), prev.n, nullptr, prev.fv_node.data(), prev.fv_off.data(),
+                                   prev.fv_idx.data(), prev.fv_n, cur.desc.data(), cur.kps.data(), cur.n, cur.fv_node.data(),
+                                   cur.fv_off.data(), cur.fv_idx.data(), cur.fv_n, 0.7f, 1, match_f.data(), &nm));
+            nm_bow += nm;
+            const double t4 = now_ms();
+            for (int i = 0; i < prev.n; i++) {           // motion-model windows around the previous positions
+                const orbx_keypoint &p = prev.kps[i];
+                qx[i] = p.x; qy[i] = p.y; qr[i] = 15.0f * powf(1.2f, (float)p.octave);
+                mn[i] = std::max(p.octave - 1, -1); mx[i] = p.octave + 1; aq[i] = p.angle;
+            }
+            CHK(orbm_search_area_best2(mt, prev.desc.data(), qx.data(), qy.data(), qr.data(), mn.data(), mx.data(), prev.n,
+                                       cur.desc.data(), nullptr, bi.data(), bd.data(), sd.data()));
+            for (int i = 0; i < prev.n; i++) m12[i] = bd[i] <= ORBM_TH_HIGH ? bi[i] : -1;
+            for (int i = 0; i < cur.n; i++) at[i] = cur.kps[i].angle;
+            nm_proj += orbm_rot_filter(aq.data(), at.data(), m12.data(), prev.n);
+            const double t5 = now_ms();
+            if (k >= 5) {
+                const double d[5] = {t1 - t0, t2 - t1, t3 - t2, t4 - t3, t5 - t4};
+                for (int i = 0; i < 5; i++) t_stage[i] += d[i];
+                t_all.push_back(t5 - t0);
+            }
+        }
+        std::swap(cur, prev);
+    }
+    std::sort(t_all.begin(), t_all.end());
+    const double med = t_all.empty() ? 0 : t_all[t_all.size() / 2];
+    const double n = t_all.empty() ? 1 : (double)t_all.size();
+    printf("{\"harness\": \"C++ through the C ABI\", \"shape\": \"%dx%d n=%d\", \"frames_timed\": %d, \"ms_per_frame_median\": %.3f, \"frames_per_s\": %.1f, "
+           "\"ms\": {\"extract\": %.3f, \"grid\": %.3f, \"bow\": %.3f, \"search_by_bow\": %.3f, \"search_by_projection\": %.3f}, "
+           "\"matches_per_frame\": {\"bow\": %.1f, \"projection\": %.1f}}\n",
+           W, H, NF, (int)t_all.size(), med, med > 0 ? 1000.0 / med : 0.0, t_stage[0] / n, t_stage[1] / n, t_stage[2] / n, t_stage[3] / n, t_stage[4] / n,
+           (double)nm_bow / std::max(K - 1, 1), (double)nm_proj / std::max(K - 1, 1));
+    orbv_destroy(voc); orbm_destroy(mt); orbx_destroy(ex);
+    return 0;
+}
