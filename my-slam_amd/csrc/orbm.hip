@@ -27,6 +27,52 @@ int mfail(int code, const char *fmt, ...)
 }
 extern "C" const char *orbm_last_error(void) { return g_merr.c_str(); }
 
+// ---- pinned staging arena (see orbm_internal.h) ----
+int orbm_arena_begin(orbm_matcher *m)
+{
+    if (m->arena_want > m->arena_cap) {          // grow between calls only: nothing is in flight here
+        MHIPCHK(hipStreamSynchronize(m->stream));
+        (void)hipHostFree(m->arena); m->arena = nullptr; m->arena_cap = 0;
+        const size_t cap = m->arena_want + m->arena_want / 2 + (64u << 10);
+        MHIPCHK(hipHostMalloc((void **)&m->arena, cap, hipHostMallocDefault));
+        m->arena_cap = cap;
+    }
+    m->arena_used = 0; m->arena_want = 0; m->npend = 0;
+    return ORBX_OK;
+}
+static void *arena_take(orbm_matcher *m, size_t bytes)
+{
+    const size_t a = (bytes + 63) & ~(size_t)63;
+    m->arena_want += a;
+    if (m->arena_used + a > m->arena_cap) return nullptr;     // this call falls back to a pageable copy; the next one has room
+    void *p = m->arena + m->arena_used;
+    m->arena_used += a;
+    return p;
+}
+int orbm_h2d(orbm_matcher *m, void *dev, const void *host, size_t bytes, hipStream_t s)
+{
+    if (bytes == 0) return ORBX_OK;
+    void *p = arena_take(m, bytes);
+    if (p) { memcpy(p, host, bytes); host = p; }
+    MHIPCHK(hipMemcpyAsync(dev, host, bytes, hipMemcpyHostToDevice, s));
+    return ORBX_OK;
+}
+int orbm_d2h(orbm_matcher *m, void *host, const void *dev, size_t bytes, hipStream_t s)
+{
+    if (bytes == 0) return ORBX_OK;
+    void *p = m->npend < 8 ? arena_take(m, bytes) : nullptr;
+    if (p) { m->pend[m->npend++] = {host, p, bytes}; host = p; }
+    MHIPCHK(hipMemcpyAsync(host, dev, bytes, hipMemcpyDeviceToHost, s));
+    return ORBX_OK;
+}
+int orbm_sync(orbm_matcher *m, hipStream_t s)
+{
+    MHIPCHK(hipStreamSynchronize(s));
+    for (int i = 0; i < m->npend; i++) memcpy(m->pend[i].dst, m->pend[i].src, m->pend[i].bytes);
+    m->npend = 0;
+    return ORBX_OK;
+}
+
 // ---- dense best/second-best: one query per thread (8 VGPRs); the train range of a workgroup is
 // staged through double-buffered 4 KiB LDS tiles and read back as wave-uniform broadcasts
 // (2 x ds_read_b128 per pair against 22 VALU ops).  gridDim.z splits the train range for occupancy; every split writes a partial
@@ -331,7 +377,7 @@ extern "C" void orbm_destroy(orbm_matcher *m)
     (void)hipFree(m->grid.kx); (void)hipFree(m->grid.ky); (void)hipFree(m->grid.koct); (void)hipFree(m->grid.cell_start);
     (void)hipFree(m->grid.items); (void)hipFree(m->grid.cell_of); (void)hipFree(m->d_qf); (void)hipFree(m->d_qi); (void)hipFree(m->d_skip);
     if (m->stream) (void)hipStreamDestroy(m->stream);
-    (void)hipHostFree(m->h_pin);
+    (void)hipHostFree(m->h_pin); (void)hipHostFree(m->arena);
     delete m;
 }
 
@@ -404,16 +450,17 @@ extern "C" int orbm_best2(orbm_matcher *m, const uint8_t *q, int nq, const uint8
     if (nq == 0) return ORBX_OK;
     if (!q || !best_idx || !best_d || !second_d || (nt > 0 && !t)) return mfail(ORBX_E_INVALID, "NULL buffer");
     MHIPCHK(hipSetDevice(m->device));
+    { int rc_ = orbm_arena_begin(m); if (rc_ != ORBX_OK) return rc_; }
     hipStream_t s = m->stream;
-    MHIPCHK(hipMemcpyAsync(m->d_q, q, (size_t)nq * 32, hipMemcpyHostToDevice, s));
-    if (nt > 0) MHIPCHK(hipMemcpyAsync(m->d_t, t, (size_t)nt * 32, hipMemcpyHostToDevice, s));
+    { int rc_ = orbm_h2d(m, m->d_q, q, (size_t)nq * 32, s); if (rc_ != ORBX_OK) return rc_; }
+    if (nt > 0) { int rc_ = orbm_h2d(m, m->d_t, t, (size_t)nt * 32, s); if (rc_ != ORBX_OK) return rc_; }
     int32_t *o_bi = m->d_out, *o_bd = m->d_out + nq, *o_sd = m->d_out + 2 * (size_t)nq;
     if (cand_off) {
         int total = 0;
         int rc = check_csr(cand_off, cand_idx, nq, nt, m->max_pairs, &total);
         if (rc != ORBX_OK) return rc;
-        MHIPCHK(hipMemcpyAsync(m->d_off, cand_off, ((size_t)nq + 1) * 4, hipMemcpyHostToDevice, s));
-        if (total > 0) MHIPCHK(hipMemcpyAsync(m->d_idx, cand_idx, (size_t)total * 4, hipMemcpyHostToDevice, s));
+        { int rc_ = orbm_h2d(m, m->d_off, cand_off, ((size_t)nq + 1) * 4, s); if (rc_ != ORBX_OK) return rc_; }
+        if (total > 0) { int rc_ = orbm_h2d(m, m->d_idx, cand_idx, (size_t)total * 4, s); if (rc_ != ORBX_OK) return rc_; }
         hipLaunchKernelGGL(k_best2_csr, dim3((nq + 3) / 4), dim3(M_THREADS), 0, s, m->d_q, nq, m->d_t, m->d_off, m->d_idx, o_bi, o_bd, o_sd);
     } else {
         const int S = pick_splits(nq, 1, nt);
@@ -424,10 +471,10 @@ extern "C" int orbm_best2(orbm_matcher *m, const uint8_t *q, int nq, const uint8
         hipLaunchKernelGGL(k_merge_best2, dim3((nq + M_THREADS - 1) / M_THREADS), dim3(M_THREADS), 0, s, m->d_part, S, nq, o_bi, o_bd, o_sd);
     }
     MHIPCHK(hipGetLastError());
-    MHIPCHK(hipMemcpyAsync(best_idx, o_bi, (size_t)nq * 4, hipMemcpyDeviceToHost, s));
-    MHIPCHK(hipMemcpyAsync(best_d, o_bd, (size_t)nq * 4, hipMemcpyDeviceToHost, s));
-    MHIPCHK(hipMemcpyAsync(second_d, o_sd, (size_t)nq * 4, hipMemcpyDeviceToHost, s));
-    MHIPCHK(hipStreamSynchronize(s));
+    { int rc_ = orbm_d2h(m, best_idx, o_bi, (size_t)nq * 4, s); if (rc_ != ORBX_OK) return rc_; }
+    { int rc_ = orbm_d2h(m, best_d, o_bd, (size_t)nq * 4, s); if (rc_ != ORBX_OK) return rc_; }
+    { int rc_ = orbm_d2h(m, second_d, o_sd, (size_t)nq * 4, s); if (rc_ != ORBX_OK) return rc_; }
+    { int rc_ = orbm_sync(m, s); if (rc_ != ORBX_OK) return rc_; }
     return ORBX_OK;
 }
 
@@ -439,9 +486,10 @@ extern "C" int orbm_distances(orbm_matcher *m, const uint8_t *q, int nq, const u
     if (nq == 0 || nt == 0) return ORBX_OK;
     if (!q || !t || !dist) return mfail(ORBX_E_INVALID, "NULL buffer");
     MHIPCHK(hipSetDevice(m->device));
+    { int rc_ = orbm_arena_begin(m); if (rc_ != ORBX_OK) return rc_; }
     hipStream_t s = m->stream;
-    MHIPCHK(hipMemcpyAsync(m->d_q, q, (size_t)nq * 32, hipMemcpyHostToDevice, s));
-    MHIPCHK(hipMemcpyAsync(m->d_t, t, (size_t)nt * 32, hipMemcpyHostToDevice, s));
+    { int rc_ = orbm_h2d(m, m->d_q, q, (size_t)nq * 32, s); if (rc_ != ORBX_OK) return rc_; }
+    { int rc_ = orbm_h2d(m, m->d_t, t, (size_t)nt * 32, s); if (rc_ != ORBX_OK) return rc_; }
     long long total;
     if (cand_off) {
         int tot = 0;
@@ -449,8 +497,8 @@ extern "C" int orbm_distances(orbm_matcher *m, const uint8_t *q, int nq, const u
         if (rc != ORBX_OK) return rc;
         total = tot;
         if (total == 0) return ORBX_OK;
-        MHIPCHK(hipMemcpyAsync(m->d_off, cand_off, ((size_t)nq + 1) * 4, hipMemcpyHostToDevice, s));
-        MHIPCHK(hipMemcpyAsync(m->d_idx, cand_idx, (size_t)total * 4, hipMemcpyHostToDevice, s));
+        { int rc_ = orbm_h2d(m, m->d_off, cand_off, ((size_t)nq + 1) * 4, s); if (rc_ != ORBX_OK) return rc_; }
+        { int rc_ = orbm_h2d(m, m->d_idx, cand_idx, (size_t)total * 4, s); if (rc_ != ORBX_OK) return rc_; }
         hipLaunchKernelGGL(k_dist_csr, dim3((unsigned)((total + M_THREADS - 1) / M_THREADS)), dim3(M_THREADS), 0, s,
                            m->d_q, nq, m->d_t, m->d_off, m->d_idx, (int)total, m->d_out);
     } else {
@@ -461,8 +509,8 @@ extern "C" int orbm_distances(orbm_matcher *m, const uint8_t *q, int nq, const u
                            m->d_q, nq, m->d_t, nt, m->d_out);
     }
     MHIPCHK(hipGetLastError());
-    MHIPCHK(hipMemcpyAsync(dist, m->d_out, (size_t)total * 4, hipMemcpyDeviceToHost, s));
-    MHIPCHK(hipStreamSynchronize(s));
+    { int rc_ = orbm_d2h(m, dist, m->d_out, (size_t)total * 4, s); if (rc_ != ORBX_OK) return rc_; }
+    { int rc_ = orbm_sync(m, s); if (rc_ != ORBX_OK) return rc_; }
     return ORBX_OK;
 }
 
@@ -551,8 +599,9 @@ extern "C" int orbm_search_by_bow(orbm_matcher *m,
     // merge-join of the two ascending node lists (:178-262); queries = usable key-frame features in visiting order
     struct Q { int kf, f_node; };
     std::vector<Q> qs;
-    std::vector<int32_t> off(1, 0);
-    std::vector<uint8_t> qdesc;
+    std::vector<int32_t> off;
+    qs.reserve((size_t)n_kf); off.reserve((size_t)n_kf + 1);
+    off.push_back(0);
     long long pairs = 0;
     for (int a = 0, b = 0; a < fv_kf_n && b < fv_f_n;) {
         if (fv_kf_node[a] == fv_f_node[b]) {
@@ -564,7 +613,6 @@ extern "C" int orbm_search_by_bow(orbm_matcher *m,
                 qs.push_back({ikf, b});
                 pairs += nb;
                 off.push_back((int32_t)pairs);
-                qdesc.insert(qdesc.end(), desc_kf + (size_t)ikf * 32, desc_kf + (size_t)ikf * 32 + 32);
             }
             a++; b++;
         } else if (fv_kf_node[a] < fv_f_node[b]) a++;   // lower_bound on an ascending list == advance
@@ -572,12 +620,17 @@ extern "C" int orbm_search_by_bow(orbm_matcher *m,
     }
     const int nq = (int)qs.size();
     if (nq == 0 || pairs == 0) return ORBX_OK;
-    if (nq > m->max_q) return mfail(ORBX_E_CAPACITY, "%d key-frame features to match, matcher sized for %d queries", nq, m->max_q);
     if (pairs > m->max_pairs) return mfail(ORBX_E_CAPACITY, "%lld candidate pairs, matcher sized for %d", pairs, m->max_pairs);
-    // pinned staging block: [nq x 32 query descriptors | n_f x 32 frame descriptors | nq+1 offsets | pairs indices | pairs distances]
+    // Usual case (both frames below 65536 features): the key frame's descriptor block goes up as it is and every pair is
+    // (key-frame feature << 16 | frame feature).  Otherwise the query descriptors are compacted and the kernel finds a
+    // pair's query by binary search over the offsets.
+    const bool packed16 = n_kf < 65536 && n_f < 65536;
+    const int nq_up = packed16 ? n_kf : nq;
+    if (nq_up > m->max_q) return mfail(ORBX_E_CAPACITY, "%d key-frame descriptors, matcher sized for %d queries", nq_up, m->max_q);
+    // pinned staging block: [query descriptors | n_f x 32 frame descriptors | nq+1 offsets | pairs indices | pairs distances]
     MHIPCHK(hipSetDevice(m->device));
     hipStream_t s = m->stream;
-    const size_t o_q = 0, o_t = o_q + (size_t)nq * 32, o_off = o_t + (size_t)n_f * 32, o_idx = o_off + ((size_t)nq + 1) * 4;
+    const size_t o_q = 0, o_t = o_q + (size_t)nq_up * 32, o_off = o_t + (size_t)n_f * 32, o_idx = o_off + ((size_t)nq + 1) * 4;
     const size_t o_dist = o_idx + (size_t)pairs * 4, need = o_dist + (size_t)pairs * 4;
     if (need > m->h_pin_bytes) {
         MHIPCHK(hipStreamSynchronize(s));
@@ -585,31 +638,30 @@ extern "C" int orbm_search_by_bow(orbm_matcher *m,
         MHIPCHK(hipHostMalloc((void **)&m->h_pin, need + need / 2, hipHostMallocDefault));
         m->h_pin_bytes = need + need / 2;
     }
-    memcpy(m->h_pin + o_q, qdesc.data(), (size_t)nq * 32);
+    if (packed16) memcpy(m->h_pin + o_q, desc_kf, (size_t)n_kf * 32);
+    else for (int i = 0; i < nq; i++) memcpy(m->h_pin + o_q + (size_t)i * 32, desc_kf + (size_t)qs[i].kf * 32, 32);
     memcpy(m->h_pin + o_t, desc_f, (size_t)n_f * 32);
-    memcpy(m->h_pin + o_off, off.data(), ((size_t)nq + 1) * 4);
     int32_t *idx = reinterpret_cast<int32_t *>(m->h_pin + o_idx);
     const int32_t *dist = reinterpret_cast<const int32_t *>(m->h_pin + o_dist);
     for (int i = 0; i < nq; i++) {
         const int b = qs[i].f_node;
+        const uint32_t hi = packed16 ? (uint32_t)qs[i].kf << 16 : 0u;
         int32_t *dst = idx + off[i];
         for (int c = fv_f_off[b]; c < fv_f_off[b + 1]; c++) {
             const int fi = fv_f_idx[c];
             if (fi < 0 || fi >= n_f) return mfail(ORBX_E_INVALID, "frame feature index %d outside [0,%d)", fi, n_f);
-            *dst++ = fi;
+            *dst++ = (int32_t)(hi | (uint32_t)fi);
         }
     }
-    MHIPCHK(hipMemcpyAsync(m->d_q, m->h_pin + o_q, (size_t)nq * 32, hipMemcpyHostToDevice, s));
+    MHIPCHK(hipMemcpyAsync(m->d_q, m->h_pin + o_q, (size_t)nq_up * 32, hipMemcpyHostToDevice, s));
     MHIPCHK(hipMemcpyAsync(m->d_t, m->h_pin + o_t, (size_t)n_f * 32, hipMemcpyHostToDevice, s));
-    if (nq < 65536 && n_f < 65536) {   // the usual case: ship (query << 16 | train) per pair
-        for (int i = 0; i < nq; i++)
-            for (int c = off[i]; c < off[i + 1]; c++) idx[c] |= (int32_t)((uint32_t)i << 16);
-        MHIPCHK(hipMemcpyAsync(m->d_idx, m->h_pin + o_idx, (size_t)pairs * 4, hipMemcpyHostToDevice, s));
+    MHIPCHK(hipMemcpyAsync(m->d_idx, m->h_pin + o_idx, (size_t)pairs * 4, hipMemcpyHostToDevice, s));
+    if (packed16) {
         hipLaunchKernelGGL(k_dist_pairs16, dim3((unsigned)((pairs + M_THREADS - 1) / M_THREADS)), dim3(M_THREADS), 0, s,
                            m->d_q, m->d_t, reinterpret_cast<const uint32_t *>(m->d_idx), (int)pairs, m->d_out);
     } else {
+        memcpy(m->h_pin + o_off, off.data(), ((size_t)nq + 1) * 4);
         MHIPCHK(hipMemcpyAsync(m->d_off, m->h_pin + o_off, ((size_t)nq + 1) * 4, hipMemcpyHostToDevice, s));
-        MHIPCHK(hipMemcpyAsync(m->d_idx, m->h_pin + o_idx, (size_t)pairs * 4, hipMemcpyHostToDevice, s));
         hipLaunchKernelGGL(k_dist_csr, dim3((unsigned)((pairs + M_THREADS - 1) / M_THREADS)), dim3(M_THREADS), 0, s,
                            m->d_q, nq, m->d_t, m->d_off, m->d_idx, (int)pairs, m->d_out);
     }
@@ -617,7 +669,6 @@ extern "C" int orbm_search_by_bow(orbm_matcher *m,
     MHIPCHK(hipMemcpyAsync(m->h_pin + o_dist, m->d_out, (size_t)pairs * 4, hipMemcpyDeviceToHost, s));
     MHIPCHK(hipStreamSynchronize(s));
     // sequential selection (:199-246)
-    const bool packed16 = nq < 65536 && n_f < 65536;
     int32_t hist[ORBM_HISTO_LENGTH] = {0};
     std::vector<int> bin_of((size_t)n_f, -1);
     const float factor = 1.0f / ORBM_HISTO_LENGTH;

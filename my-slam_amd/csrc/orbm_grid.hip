@@ -235,6 +235,7 @@ extern "C" int orbm_grid_build(orbm_matcher *m, const orbx_keypoint *kps_un, int
     if (n > 0 && !kps_un) return mfail(ORBX_E_INVALID, "NULL keypoints");
     if (!(max_x > min_x) || !(max_y > min_y)) return mfail(ORBX_E_INVALID, "empty image bounds");
     MHIPCHK(hipSetDevice(m->device));
+    { int rc_ = orbm_arena_begin(m); if (rc_ != ORBX_OK) return rc_; }
     int rc = ensure_grid(m);
     if (rc != ORBX_OK) return rc;
     m->grid.min_x = min_x; m->grid.min_y = min_y;
@@ -247,10 +248,10 @@ extern "C" int orbm_grid_build(orbm_matcher *m, const orbx_keypoint *kps_un, int
     const size_t have = std::max<size_t>((size_t)3 * m->max_q, (size_t)m->max_pairs) * 4;
     void *tmp = nullptr;
     if (need > have) { MHIPCHK(hipMalloc(&tmp, need)); d_kps = reinterpret_cast<orbx_keypoint *>(tmp); }
-    if (n > 0) MHIPCHK(hipMemcpyAsync(d_kps, kps_un, need, hipMemcpyHostToDevice, s));
+    if (n > 0) { int rc_ = orbm_h2d(m, d_kps, kps_un, need, s); if (rc_ != ORBX_OK) return rc_; }
     hipLaunchKernelGGL(k_grid_build, dim3(1), dim3(G_THREADS), 0, s, m->grid, d_kps);
     MHIPCHK(hipGetLastError());
-    MHIPCHK(hipStreamSynchronize(s));
+    { int rc_ = orbm_sync(m, s); if (rc_ != ORBX_OK) return rc_; }
     if (tmp) (void)hipFree(tmp);
     m->grid_ok = true;
     return ORBX_OK;
@@ -261,11 +262,11 @@ static int upload_windows(orbm_matcher *m, const float *x, const float *y, const
 {
     int rc = ensure_query_staging(m, (size_t)nq);
     if (rc != ORBX_OK) return rc;
-    MHIPCHK(hipMemcpyAsync(m->d_qf, x, (size_t)nq * 4, hipMemcpyHostToDevice, s));
-    MHIPCHK(hipMemcpyAsync(m->d_qf + m->qf_elems, y, (size_t)nq * 4, hipMemcpyHostToDevice, s));
-    MHIPCHK(hipMemcpyAsync(m->d_qf + 2 * m->qf_elems, r, (size_t)nq * 4, hipMemcpyHostToDevice, s));
-    MHIPCHK(hipMemcpyAsync(m->d_qi, mn, (size_t)nq * 4, hipMemcpyHostToDevice, s));
-    MHIPCHK(hipMemcpyAsync(m->d_qi + m->qf_elems, mx, (size_t)nq * 4, hipMemcpyHostToDevice, s));
+    { int rc_ = orbm_h2d(m, m->d_qf, x, (size_t)nq * 4, s); if (rc_ != ORBX_OK) return rc_; }
+    { int rc_ = orbm_h2d(m, m->d_qf + m->qf_elems, y, (size_t)nq * 4, s); if (rc_ != ORBX_OK) return rc_; }
+    { int rc_ = orbm_h2d(m, m->d_qf + 2 * m->qf_elems, r, (size_t)nq * 4, s); if (rc_ != ORBX_OK) return rc_; }
+    { int rc_ = orbm_h2d(m, m->d_qi, mn, (size_t)nq * 4, s); if (rc_ != ORBX_OK) return rc_; }
+    { int rc_ = orbm_h2d(m, m->d_qi + m->qf_elems, mx, (size_t)nq * 4, s); if (rc_ != ORBX_OK) return rc_; }
     return ORBX_OK;
 }
 
@@ -280,6 +281,7 @@ extern "C" int orbm_features_in_area(orbm_matcher *m, const float *x, const floa
     if (nq == 0) return 0;
     if (!x || !y || !r || !min_level || !max_level) return mfail(ORBX_E_INVALID, "NULL window array");
     MHIPCHK(hipSetDevice(m->device));
+    { int rc_ = orbm_arena_begin(m); if (rc_ != ORBX_OK) return rc_; }
     hipStream_t s = m->stream;
     int rc = upload_windows(m, x, y, r, min_level, max_level, nq, s);
     if (rc != ORBX_OK) return rc;
@@ -290,20 +292,20 @@ extern "C" int orbm_features_in_area(orbm_matcher *m, const float *x, const floa
                        nq, d_cnt, (const int32_t *)nullptr, (int32_t *)nullptr);
     MHIPCHK(hipGetLastError());
     std::vector<int32_t> cnt(nq);
-    MHIPCHK(hipMemcpyAsync(cnt.data(), d_cnt, (size_t)nq * 4, hipMemcpyDeviceToHost, s));
-    MHIPCHK(hipStreamSynchronize(s));
+    { int rc_ = orbm_d2h(m, cnt.data(), d_cnt, (size_t)nq * 4, s); if (rc_ != ORBX_OK) return rc_; }
+    { int rc_ = orbm_sync(m, s); if (rc_ != ORBX_OK) return rc_; }
     for (int i = 0; i < nq; i++) cand_off[i + 1] = cand_off[i] + cnt[i];
     const int total = cand_off[nq];
     if (total > cap_idx) return mfail(ORBX_E_CAPACITY, "%d candidates, caller capacity %d", total, cap_idx);
     if (total == 0) return 0;
     if (!cand_idx) return mfail(ORBX_E_INVALID, "cand_idx is NULL");
     if (total > m->max_pairs) return mfail(ORBX_E_CAPACITY, "%d candidates, matcher sized for %d pairs", total, m->max_pairs);
-    MHIPCHK(hipMemcpyAsync(d_off, cand_off, (size_t)nq * 4, hipMemcpyHostToDevice, s));
+    { int rc_ = orbm_h2d(m, d_off, cand_off, (size_t)nq * 4, s); if (rc_ != ORBX_OK) return rc_; }
     hipLaunchKernelGGL(k_area_list<1>, grid, dim3(M_THREADS), 0, s, m->grid, m->d_qf, m->d_qf + Q, m->d_qf + 2 * Q, m->d_qi, m->d_qi + Q,
                        nq, (int32_t *)nullptr, d_off, m->d_idx);
     MHIPCHK(hipGetLastError());
-    MHIPCHK(hipMemcpyAsync(cand_idx, m->d_idx, (size_t)total * 4, hipMemcpyDeviceToHost, s));
-    MHIPCHK(hipStreamSynchronize(s));
+    { int rc_ = orbm_d2h(m, cand_idx, m->d_idx, (size_t)total * 4, s); if (rc_ != ORBX_OK) return rc_; }
+    { int rc_ = orbm_sync(m, s); if (rc_ != ORBX_OK) return rc_; }
     return total;
 }
 
@@ -337,25 +339,26 @@ extern "C" int orbm_search_area_best2(orbm_matcher *m, const uint8_t *qdesc, con
     if (!qdesc || !x || !y || !r || !min_level || !max_level || !best_idx || !best_d || !second_d || (m->grid.n > 0 && !train_desc))
         return mfail(ORBX_E_INVALID, "NULL buffer");
     MHIPCHK(hipSetDevice(m->device));
+    { int rc_ = orbm_arena_begin(m); if (rc_ != ORBX_OK) return rc_; }
     hipStream_t s = m->stream;
     int rc = upload_windows(m, x, y, r, min_level, max_level, nq, s);
     if (rc != ORBX_OK) return rc;
     const size_t Q = m->qf_elems;
-    MHIPCHK(hipMemcpyAsync(m->d_q, qdesc, (size_t)nq * 32, hipMemcpyHostToDevice, s));
-    if (m->grid.n > 0) MHIPCHK(hipMemcpyAsync(m->d_t, train_desc, (size_t)m->grid.n * 32, hipMemcpyHostToDevice, s));
+    { int rc_ = orbm_h2d(m, m->d_q, qdesc, (size_t)nq * 32, s); if (rc_ != ORBX_OK) return rc_; }
+    if (m->grid.n > 0) { int rc_ = orbm_h2d(m, m->d_t, train_desc, (size_t)m->grid.n * 32, s); if (rc_ != ORBX_OK) return rc_; }
     const uint8_t *d_skip = nullptr;
     if (skip && m->grid.n > 0) {
         if (!m->d_skip) MHIPCHK(hipMalloc((void **)&m->d_skip, (size_t)m->max_t));
-        MHIPCHK(hipMemcpyAsync(m->d_skip, skip, (size_t)m->grid.n, hipMemcpyHostToDevice, s));
+        { int rc_ = orbm_h2d(m, m->d_skip, skip, (size_t)m->grid.n, s); if (rc_ != ORBX_OK) return rc_; }
         d_skip = m->d_skip;
     }
     int32_t *o_bi = m->d_out, *o_bd = m->d_out + nq, *o_sd = m->d_out + 2 * (size_t)nq;
     rc = orbm_search_area_best2_device(m, m->d_q, m->d_qf, m->d_qf + Q, m->d_qf + 2 * Q, m->d_qi, m->d_qi + Q, nq, m->d_t, d_skip,
                                        o_bi, o_bd, o_sd, s);
     if (rc != ORBX_OK) return rc;
-    MHIPCHK(hipMemcpyAsync(best_idx, o_bi, (size_t)nq * 4, hipMemcpyDeviceToHost, s));
-    MHIPCHK(hipMemcpyAsync(best_d, o_bd, (size_t)nq * 4, hipMemcpyDeviceToHost, s));
-    MHIPCHK(hipMemcpyAsync(second_d, o_sd, (size_t)nq * 4, hipMemcpyDeviceToHost, s));
-    MHIPCHK(hipStreamSynchronize(s));
+    { int rc_ = orbm_d2h(m, best_idx, o_bi, (size_t)nq * 4, s); if (rc_ != ORBX_OK) return rc_; }
+    { int rc_ = orbm_d2h(m, best_d, o_bd, (size_t)nq * 4, s); if (rc_ != ORBX_OK) return rc_; }
+    { int rc_ = orbm_d2h(m, second_d, o_sd, (size_t)nq * 4, s); if (rc_ != ORBX_OK) return rc_; }
+    { int rc_ = orbm_sync(m, s); if (rc_ != ORBX_OK) return rc_; }
     return ORBX_OK;
 }

@@ -51,5 +51,14 @@ struct orbm_matcher {
     float *d_qf = nullptr; int32_t *d_qi = nullptr; uint8_t *d_skip = nullptr;   // window-query staging (lazy)
     size_t qf_elems = 0;
     uint8_t *h_pin = nullptr; size_t h_pin_bytes = 0;   // pinned staging of orbm_search_by_bow (lazy)
+    // pinned bump arena for the host-buffer entry points: pageable hipMemcpyAsync is a staged, synchronous copy of tens of
+    // microseconds each; through pinned memory the copies of one call queue up behind each other and cost one round trip
+    uint8_t *arena = nullptr; size_t arena_cap = 0, arena_used = 0, arena_want = 0;
+    struct Pend { void *dst; const void *src; size_t bytes; };
+    Pend pend[8]; int npend = 0;
 };
+int orbm_arena_begin(orbm_matcher *m);                                                    // start of a host-API call
+int orbm_h2d(orbm_matcher *m, void *dev, const void *host, size_t bytes, hipStream_t s);   // staged host -> device copy
+int orbm_d2h(orbm_matcher *m, void *host, const void *dev, size_t bytes, hipStream_t s);   // staged; lands in host at orbm_sync()
+int orbm_sync(orbm_matcher *m, hipStream_t s);                                            // synchronise + deliver the D2H copies
 
