@@ -9,9 +9,7 @@
 #define DW_RAW_STRIDE_H 48   // = DW_RAW_STRIDE below (host-side table builder)
 #define DESC_R_H 18          // = DESC_R
 
-__constant__ unsigned long long c_umax_nib;   // umax[v] in nibble v (v = 0..15)
 __constant__ int c_gauss[7];
-__constant__ signed char c_pattern[1024];
 // Per-task constants of the IC_Angle dword tasks (31 rows x dwords 1..9 of the raw row that touch the disc: 213, padded to 256):
 //   x = weights (u + 32 per byte, 0 outside the disc), y = 1 per byte inside the disc, z = byte offset of the dword in
 //   the raw tile, w = v (row offset, -15..15).  Replaces ~20 instructions of mask arithmetic per task.
@@ -28,14 +26,9 @@ __constant__ float4 c_pat_f[256];
 
 int orbx_upload_constants(const int umax[16], const int gauss_k[7])
 {
-    unsigned long long nib = 0;
-    for (int v = 0; v < 16; v++) {
+    for (int v = 0; v < 16; v++)
         if (umax[v] < 0 || umax[v] > 15) return -1;
-        nib |= (unsigned long long)umax[v] << (4 * v);
-    }
-    if (hipMemcpyToSymbol(HIP_SYMBOL(c_umax_nib), &nib, sizeof(nib)) != hipSuccess) return -1;
     if (hipMemcpyToSymbol(HIP_SYMBOL(c_gauss), gauss_k, sizeof(int) * 7) != hipSuccess) return -1;
-    if (hipMemcpyToSymbol(HIP_SYMBOL(c_pattern), ORBX_PATTERN, 1024) != hipSuccess) return -1;
     static uint4 mt[256];
     int nmt = 0;
     for (int t = 0; t < 256; t++) mt[t] = make_uint4(0u, 0u, 0u, 0u);
