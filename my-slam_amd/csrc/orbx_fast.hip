@@ -27,16 +27,18 @@
 #define FAST_REJECT_POINTS 4   // stage-1 reject on 4 or 8 circle points (both necessary conditions; results identical)
 #endif
 #define FAST_PADL 4      // left pad (bytes) of every tile row so that dword g-1 exists for every group
-#define FAST_CLIST 256   // corners listed per cell before NMS falls back to scanning the whole score map
+#define FAST_CLIST 224   // corners listed per cell before NMS falls back to scanning the whole score map
 
 template <int TS, int TH, int ZS>   // tile row stride (bytes, multiple of 4), tile rows, score-map stride/rows
 struct FastLds {
     uint8_t tile[TS * TH];
     uint8_t smap[ZS * ZS];
-    uint16_t queue[392];   // < 128 pending + <= 256 appended per stage-1 step; [391] = trash slot
+    uint16_t queue[384];   // < 128 pending + <= 256 appended per stage-1 step (entries 0..382); [383] = trash slot.
+                           // Dead once stage 2 has drained it: the NMS ballot masks ((ZS * ZS + 63) / 64 x 8 B) reuse it.
     uint16_t clist[FAST_CLIST];
-    unsigned long long masks[(ZS * ZS + 63) / 64];
 };
+// 52-byte tile rows, 384-entry queue and 224-entry corner list: 5104 B per wave, 20416 B per workgroup -> 8 workgroups
+// (32 waves) per CU by LDS instead of 7.
 
 typedef unsigned short us2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ us2 as_us2(uint32_t v) { return __builtin_bit_cast(us2, v); }
@@ -193,7 +195,8 @@ __global__ __launch_bounds__(FAST_THREADS) void k_fast_cells(OrbxPlan plan, Orbx
             S.tile[y * TS + FAST_PADL + 1 + x] = img[(long long)y * L.stride + iniX + x];
         }
     } else {
-        constexpr int NDW = TS / 4 - 2, RPP = 64 / NDW;   // payload dwords per tile row, rows per pass
+        constexpr int NDW = (TH + 7) / 4, RPP = 64 / NDW;   // payload dwords per tile row (LDS dwords 1 .. NDW), rows per pass
+        static_assert(TS % 4 == 0 && TS >= 4 + 4 * NDW, "tile row too short");
         const int ndw = (tw + 4) >> 2;                    // LDS dwords 1 .. ndw hold tile columns -1 .. tw-1
         static_assert(NDW == 12 || NDW == 18, "lane / NDW below is written for these");
         const int r_in = NDW == 12 ? (int)(__umul24((uint32_t)lane, 43u) >> 9) : (int)(__umul24((uint32_t)lane, 57u) >> 10);   // lane / NDW, lane < 64
@@ -290,10 +293,10 @@ __global__ __launch_bounds__(FAST_THREADS) void k_fast_cells(OrbxPlan plan, Orbx
             const int e0 = orbx_prefix_cnt(b0, qn), e1 = orbx_prefix_cnt(b1, qn + n0);
             const int e2 = orbx_prefix_cnt(b2, qn + n0 + n1), e3 = orbx_prefix_cnt(b3, qn + n0 + n1 + n2);
             const int pz = (zy << 6) + zx0;          // (zy << 6) | zx for every pixel with 0 <= zx < 64
-            S.queue[k0 ? e0 : 391] = (uint16_t)pz;
-            S.queue[k1 ? e1 : 391] = (uint16_t)(pz + 1);
-            S.queue[k2 ? e2 : 391] = (uint16_t)(pz + 2);
-            S.queue[k3 ? e3 : 391] = (uint16_t)(pz + 3);
+            S.queue[k0 ? e0 : 383] = (uint16_t)pz;
+            S.queue[k1 ? e1 : 383] = (uint16_t)(pz + 1);
+            S.queue[k2 ? e2 : 383] = (uint16_t)(pz + 2);
+            S.queue[k3 ? e3 : 383] = (uint16_t)(pz + 3);
             qn += n0 + n1 + n2 + __popcll(b3);
             while (qn >= 128) {
                 WSYNC();
@@ -321,6 +324,8 @@ __global__ __launch_bounds__(FAST_THREADS) void k_fast_cells(OrbxPlan plan, Orbx
 
         // ---- stage 3: NMS (strictly greater than all 8 neighbours; outside the cell zone counts as 0).
         // Items are the listed corners, or every zone pixel if the list overflowed. ----
+        unsigned long long *nms_masks = reinterpret_cast<unsigned long long *>(S.queue);   // the queue is empty and idle from here on
+        static_assert(sizeof(S.queue) >= ((ZS * ZS + 63) / 64) * 8 && (TS * TH + ZS * ZS) % 8 == 0, "mask alias");
         int total = 0;
         const int nitem = cl_over ? npx : ncl;
         const int niter = (nitem + 63) >> 6;
@@ -340,7 +345,7 @@ __global__ __launch_bounds__(FAST_THREADS) void k_fast_cells(OrbxPlan plan, Orbx
                 ismax = s > nm;      // s > nm >= 0 implies s > 0
             }
             const unsigned long long mm = __builtin_amdgcn_ballot_w64(ismax);
-            if (lane == 0) S.masks[it] = mm;
+            if (lane == 0) nms_masks[it] = mm;
             total += __popcll(mm);
         }
         FT(3);
@@ -353,7 +358,7 @@ __global__ __launch_bounds__(FAST_THREADS) void k_fast_cells(OrbxPlan plan, Orbx
         OrbxCand *out = wk.cand + (long long)f * plan.cand_frame + L.cand_off;
         int written = 0;
         for (int it = 0; it < niter; it++) {
-            const unsigned long long mm = S.masks[it];
+            const unsigned long long mm = nms_masks[it];
             if (mm == 0) continue;
             const int idx = it * 64 + lane;
             if ((mm >> lane) & 1ull) {
@@ -424,8 +429,8 @@ void orbx_launch_fast(const OrbxPlan &plan, const OrbxWork &wk, int nframes, int
     const int wg_per_frame = (cell_hi - cell_lo + FAST_THREADS / 64 - 1) / (FAST_THREADS / 64);
     const int nwg = wg_per_frame * nframes;
     dim3 grid((nwg + 7) & ~7);
-    if (maxcell <= 38)   // tile <= 44x44, zone <= 38x38; row = 4 pad + 3 + 44 + over-read -> 56 B
-        hipLaunchKernelGGL((k_fast_cells<56, 44, 40>), grid, dim3(FAST_THREADS), 0, s, plan, wk, l0_aligned, cell_lo, cell_hi, wg_per_frame, nwg, wg_per_frame > 1 ? (uint32_t)((1ull << 32) / (unsigned)wg_per_frame + 1) : 0u);
+    if (maxcell <= 38)   // tile <= 44x44, zone <= 38x38; row = 4 pad + 1 + 44 + over-read (3) -> 52 B
+        hipLaunchKernelGGL((k_fast_cells<52, 44, 40>), grid, dim3(FAST_THREADS), 0, s, plan, wk, l0_aligned, cell_lo, cell_hi, wg_per_frame, nwg, wg_per_frame > 1 ? (uint32_t)((1ull << 32) / (unsigned)wg_per_frame + 1) : 0u);
     else                 // cells of tiny levels: tile <= 66x66, zone <= 60x60
         hipLaunchKernelGGL((k_fast_cells<80, 66, 64>), grid, dim3(FAST_THREADS), 0, s, plan, wk, l0_aligned, cell_lo, cell_hi, wg_per_frame, nwg, wg_per_frame > 1 ? (uint32_t)((1ull << 32) / (unsigned)wg_per_frame + 1) : 0u);
 }
