@@ -46,6 +46,18 @@ while time.time() - t0 < budget:
         a, b = kps[name], okps[name]
         assert np.array_equal(a.view(np.uint32) if a.dtype.kind == "f" else a, b.view(np.uint32) if b.dtype.kind == "f" else b), "%s: %s" % (name, tag)
     assert np.array_equal(desc, odesc), "descriptors: " + tag
+    if n_ok % 7 == 0:     # the batched path (other grids, XCD-aware order over several frames) must give the same frames
+        B = int(rng.integers(2, 6))
+        stack = np.stack([np.ascontiguousarray(img), np.ascontiguousarray(img[::-1, ::-1]), np.ascontiguousarray(img)] + [np.ascontiguousarray(img)] * (B - 3))[:B]
+        exb = M.ORBextractor(nf, sf, nl, ini, mn, max_width=W, max_height=H, max_batch=B)
+        res = exb.extract_batch(stack)
+        for b in (0, B - 1):
+            assert len(res[b][0]) == len(kps) and np.array_equal(res[b][1], desc), "batch frame %d: %s" % (b, tag)
+            assert np.array_equal(res[b][0]["x"], kps["x"]) and np.array_equal(res[b][0]["angle"].view(np.uint32), kps["angle"].view(np.uint32)), "batch kps: " + tag
+        if B > 1:
+            ok2, od2, _ = O.Extractor(nf, sf, nl, ini, mn).extract(stack[1])
+            assert len(res[1][0]) == len(ok2) and np.array_equal(res[1][1], od2), "batch frame 1 (flipped): " + tag
+        del exb
     n_ok += 1; del ex
     if n_ok % 20 == 0:
         print("%d cases ok (%d rejected shapes), %.0f s" % (n_ok, n_rej, time.time() - t0), flush=True)
