@@ -121,6 +121,62 @@ def cpu_baseline(frames, nfeatures, budget_s=12.0, all_cores_s=8.0):
     return out
 
 
+def pipelined_pass(pkg, torch, frames, W, H, B, NF, device, do_match, steps, nk_per_step, nstreams=2):
+    """Throughput of the same steps issued round-robin on `nstreams` streams, each with its own handles and buffers and one
+    captured HIP graph per step (13 kernels, one host call)."""
+    class Pipe:
+        pass
+    pipes = []
+    for _ in range(nstreams):
+        p = Pipe()
+        p.ex = pkg.ORBextractor(NF, 1.2, 8, 20, 7, device=device, max_width=W, max_height=H, max_batch=B)
+        cap = p.ex.cap
+        p.kps = torch.zeros((B, cap, 7), device="cuda"); p.desc = torch.zeros((B, cap, 32), dtype=torch.uint8, device="cuda")
+        p.cnt = torch.zeros(B, dtype=torch.int32, device="cuda"); p.status = torch.zeros(B, dtype=torch.int32, device="cuda")
+        p.mt = pkg.ORBmatcher(0.9, True, device=device, max_queries=cap, max_train=cap, max_pairs=1) if do_match else None
+        p.m12 = torch.full((B, cap), -1, dtype=torch.int32, device="cuda"); p.nm = torch.zeros(B, dtype=torch.int32, device="cuda")
+        p.stream = torch.cuda.Stream()
+        pipes.append(p)
+
+    def kernels(p):
+        sp = p.stream.cuda_stream
+        p.ex.extract_batch_device(frames.data_ptr(), B, W, H, frames.stride(1), frames.stride(0),
+                                  p.kps.data_ptr(), p.desc.data_ptr(), p.cnt.data_ptr(), p.status.data_ptr(), sp)
+        if do_match:
+            cap = p.ex.cap
+            p.mt.match_batch_device(p.desc.data_ptr() + cap * 32, p.kps.data_ptr() + cap * 28, p.cnt.data_ptr() + 4,
+                                    p.desc.data_ptr(), p.kps.data_ptr(), p.cnt.data_ptr(), cap, B - 1,
+                                    p.m12.data_ptr() + cap * 4, p.nm.data_ptr() + 4, stream=sp)
+    for p in pipes:                     # size the workspaces, then capture
+        kernels(p); kernels(p)
+    torch.cuda.synchronize()
+    for p in pipes:
+        p.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(p.graph, stream=p.stream):
+            kernels(p)
+    ends = [torch.cuda.Event() for _ in range(steps + 2 * nstreams)]
+
+    def run(n, base):
+        for i in range(n):
+            p = pipes[i % nstreams]
+            if i > nstreams:            # the hardware queues do not arbitrate fairly: keep the streams within a step of each other
+                p.stream.wait_event(ends[base + i - nstreams - 1])
+            with torch.cuda.stream(p.stream):
+                p.graph.replay()
+            ends[base + i].record(p.stream)
+    run(2 * nstreams, 0)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    run(steps, 2 * nstreams)
+    torch.cuda.synchronize()
+    el = (time.perf_counter() - t0) / steps
+    for p in pipes:
+        if int(p.status.abs().sum().item()) != 0 or int(p.cnt.sum().item()) != nk_per_step:
+            raise RuntimeError("pipelined pass produced different results")
+    return {"streams": nstreams, "hip_graph_per_step": True, "steps": steps, "ms_per_step": round(el * 1e3, 4),
+            "frames_per_s": round(B / el, 1), "keypoints_per_s": round(nk_per_step / el, 1)}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -134,6 +190,7 @@ def main():
     ap.add_argument("--no-overlap", action="store_true", help="do not overlap the resize chain with FAST on level 0")
     ap.add_argument("--no-match", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-pipelined", action="store_true", help="skip the extra two-stream / HIP-graph throughput pass")
     ap.add_argument("--cpu-budget", type=float, default=12.0)
     args = ap.parse_args()
 
@@ -318,6 +375,17 @@ def main():
                 "whole_path_algorithmic_GBps": round(sum(ab[k] for k in ("pyramid", "fast", "describe")) * B * world
                                                      / (elapsed / args.steps) / 1e9, 2)}
 
+    # ---- extra (N = 1): the same steps pipelined over two HIP streams, one captured HIP graph per step ----
+    # Consecutive steps are independent, so the short latency-bound kernels of one step (resize chain, quadtree, acceptance)
+    # can run underneath the VALU-bound ones of the next.  Reported beside the contract's single-stream line, never as `value`:
+    # kernels of overlapping steps time-share the GPU, so per-kernel durations (and `roofline`) are not defined in that mode.
+    pipelined = None
+    if rank == 0 and world == 1 and not args.no_pipelined:
+        try:
+            pipelined = pipelined_pass(pkg, torch, frames, W, H, B, NF, local, do_match, args.steps, nk_local)
+        except Exception as e:
+            pipelined = {"error": str(e)[:200]}
+
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         cpu = cpu_baseline(frames_np, NF, args.cpu_budget)
@@ -341,6 +409,7 @@ def main():
                        "parallelism": "frames sharded over %d GPU(s); RCCL gather of keypoint/descriptor buffers to rank 0" % world},
             "roofline": roof,
             "cpu_baseline": cpu,
+            "pipelined": pipelined,
         }
         print(json.dumps(out))
     if world > 1:

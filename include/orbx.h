@@ -117,7 +117,13 @@ int orbx_download_candidates(orbx_extractor *h, int frame, int level, int32_t *x
 /* Elapsed GPU milliseconds of the last call per stage, measured with HIP events on the stream the
  * kernels ran on: [0] pyramid, [1] fast, [2] quadtree, [3] describe (orientation+blur+rBRIEF). */
 int orbx_last_stage_ms(orbx_extractor *h, float ms[4]);
-int orbx_set_profiling(orbx_extractor *h, int enabled);
+/* mode 0 = off; 1 = time every call in isolation (the call synchronises on its last event; read with orbx_last_stage_ms);
+ * 2 = drop the stage events of the last ORBX_PROF_RING calls into the stream and never wait for them: for timing kernels
+ * while several handles run on several streams.  Read with orbx_stage_ms_ring after synchronising the stream yourself. */
+#define ORBX_PROF_RING 16
+int orbx_set_profiling(orbx_extractor *h, int mode);
+/* ms[4 * i + k]: stage k of the i-th newest profiled call (mode 2).  Returns the number of calls written (<= max_calls). */
+int orbx_stage_ms_ring(orbx_extractor *h, float *ms, int max_calls);
 
 /*
  * "next" row N3: Frame::ComputeStereoMatches (src/Frame.cc:466-640) on the GPU.  `left` and

@@ -77,6 +77,7 @@ def lib():
     L.orbx_download_candidates.argtypes = [vp, C.c_int, C.c_int, vp, C.c_int]
     L.orbx_last_stage_ms.argtypes = [vp, vp]
     L.orbx_set_profiling.argtypes = [vp, C.c_int]
+    L.orbx_stage_ms_ring.argtypes = [vp, vp, C.c_int]
     L.orbx_last_error.restype = C.c_char_p
     L.orbx_version.restype = C.c_char_p
     L.orbx_debug_sincos.argtypes = [vp, vp, vp, C.c_int]
@@ -212,6 +213,13 @@ class ORBextractor:
         ms = np.zeros(4, np.float32)
         _chk(self.L.orbx_last_stage_ms(self.h, _p(ms)))
         return ms
+
+    def stage_ms_ring(self, max_calls=16):
+        """Stage times of the last calls under set_profiling(2) (rows: newest first; the stream must be synchronised)."""
+        ms = np.zeros((max_calls, 4), np.float32)
+        n = self.L.orbx_stage_ms_ring(self.h, _p(ms), max_calls)
+        _chk(min(n, 0))
+        return ms[:n]
 
     def __call__(self, image, mask=None):
         """operator()(image, mask, keypoints, descriptors) -> (keypoints[KP_DTYPE], descriptors[n,32])."""

@@ -64,6 +64,8 @@ struct orbx_extractor {
     uint8_t *h_in = nullptr;
     orbx_keypoint *h_kps = nullptr; uint8_t *h_desc = nullptr; int32_t *h_counts = nullptr, *h_status = nullptr;
     int profiling = 0; hipEvent_t ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr}; float stage_ms[4] = {0, 0, 0, 0};
+    // profiling == 2: the stage events of the last ORBX_PROF_RING calls are recorded and never waited for by the library
+    hipEvent_t evr[ORBX_PROF_RING][5] = {}; long long ring_calls = 0;
 };
 
 // ---- A1: ORBextractor::ORBextractor tables (:412-472) ----
@@ -190,6 +192,7 @@ static void free_all(orbx_extractor *h)
     hipFree(h->d_kps); hipFree(h->d_desc); hipFree(h->d_counts); hipFree(h->d_status);
     hipHostFree(h->h_in); hipHostFree(h->h_kps); hipHostFree(h->h_desc); hipHostFree(h->h_counts); hipHostFree(h->h_status);
     for (auto &e : h->ev) if (e) hipEventDestroy(e);
+    for (auto &set : h->evr) for (auto &e : set) if (e) hipEventDestroy(e);
     for (auto &e : h->ev_join) if (e) hipEventDestroy(e);
     if (h->ev_fork) hipEventDestroy(h->ev_fork);
     for (auto &a : h->aux) if (a) hipStreamDestroy(a);
@@ -312,7 +315,27 @@ extern "C" int orbx_get_features_per_level(const orbx_extractor *h, int *q)
     return ORBX_OK;
 }
 extern "C" int orbx_capacity(const orbx_extractor *h) { return h ? h->max_plan.out_cap : 0; }
-extern "C" int orbx_set_profiling(orbx_extractor *h, int enabled) { if (!h) return ORBX_E_INVALID; h->profiling = enabled != 0; return ORBX_OK; }
+extern "C" int orbx_set_profiling(orbx_extractor *h, int mode)
+{
+    if (!h || mode < 0 || mode > 2) return fail(ORBX_E_INVALID, "profiling mode %d", mode);
+    if (mode == 2 && !h->evr[0][0]) {
+        HIPCHK(hipSetDevice(h->device));
+        for (auto &set : h->evr) for (auto &e : set) HIPCHK(hipEventCreate(&e));
+    }
+    h->profiling = mode; h->ring_calls = 0;
+    return ORBX_OK;
+}
+extern "C" int orbx_stage_ms_ring(orbx_extractor *h, float *ms, int max_calls)
+{
+    if (!h || !ms || max_calls < 0) return fail(ORBX_E_INVALID, "bad argument");
+    if (h->profiling != 2) return fail(ORBX_E_INVALID, "ring profiling is off");
+    const int n = (int)std::min<long long>(std::min<long long>(h->ring_calls, ORBX_PROF_RING), max_calls);
+    for (int i = 0; i < n; i++) {                           // newest first
+        hipEvent_t *e = h->evr[(h->ring_calls - 1 - i) % ORBX_PROF_RING];
+        for (int k = 0; k < 4; k++) HIPCHK(hipEventElapsedTime(&ms[4 * i + k], e[k], e[k + 1]));   // fails if the caller has not synchronised
+    }
+    return n;
+}
 extern "C" int orbx_last_stage_ms(orbx_extractor *h, float ms[4])
 {
     if (!h || !ms) return fail(ORBX_E_INVALID, "NULL argument");
@@ -388,7 +411,8 @@ static int enqueue(orbx_extractor *h, const uint8_t *d_images, int nframes, int 
     P.lv[0].frame_stride = frame_stride;
     h->last_input = d_images; h->last_in_stride = row_stride; h->last_in_frame = frame_stride; h->last_batch = nframes;
 
-    const bool prof = h->profiling != 0;
+    const bool prof = h->profiling == 1;          // mode 1 times one call in isolation; mode 2 only drops events into the stream
+    hipEvent_t *pe = h->profiling == 2 ? h->evr[h->ring_calls % ORBX_PROF_RING] : (prof ? h->ev : nullptr);
     if (h->need_clear) {   // the kernels leave the counters and flags zeroed; only the first call (or one after an error) clears
         HIPCHK(hipMemsetAsync(h->work.cand_count, 0, (size_t)h->max_batch * ORBX_MAX_LEVELS * ORBX_CNT_STRIDE * sizeof(uint32_t), s));
         HIPCHK(hipMemsetAsync(h->work.errflags, 0, (size_t)h->max_batch * sizeof(uint32_t), s));
@@ -402,7 +426,7 @@ static int enqueue(orbx_extractor *h, const uint8_t *d_images, int nframes, int 
     // Sub-batches on separate streams: the quadtree and the small pyramid levels are latency-bound
     // (few, long workgroups), so one half-batch's latency-bound kernels run beside the other half's
     // VALU-bound ones.  Frames are independent, so a sub-batch is only a pointer offset.
-    int nsub = (prof || nframes < 16) ? 1 : std::min(h->nsub, ORBX_MAX_SUB);
+    int nsub = (h->profiling != 0 || nframes < 16) ? 1 : std::min(h->nsub, ORBX_MAX_SUB);
     hipStream_t st[ORBX_MAX_SUB];
     OrbxPlan sp[ORBX_MAX_SUB];
     OrbxWork sw[ORBX_MAX_SUB];
@@ -422,10 +446,10 @@ static int enqueue(orbx_extractor *h, const uint8_t *d_images, int nframes, int 
         HIPCHK(hipEventRecord(h->ev_fork, s));
         for (int i = 1; i < nsub; i++) HIPCHK(hipStreamWaitEvent(st[i], h->ev_fork, 0));
     }
-    if (prof) HIPCHK(hipEventRecord(h->ev[0], s));
+    if (pe) HIPCHK(hipEventRecord(pe[0], s));
     // FAST on level 0 needs only the input, so with one sub-batch the resize chain (seven small, latency-bound
     // launches) runs on a side stream underneath it; the remaining levels' cells wait for the chain.
-    const bool overlap = !prof && nsub == 1 && h->overlap_pyr && h->nlevels > 1 && P.lv[1].cell_begin > 0;
+    const bool overlap = h->profiling == 0 && nsub == 1 && h->overlap_pyr && h->nlevels > 1 && P.lv[1].cell_begin > 0;
     if (overlap) {
         hipStream_t sa = h->aux[ORBX_MAX_SUB - 2];
         HIPCHK(hipEventRecord(h->ev_fork, s));
@@ -440,28 +464,29 @@ static int enqueue(orbx_extractor *h, const uint8_t *d_images, int nframes, int 
         for (int l = 1; l < h->nlevels; l++)
             for (int i = 0; i < nsub; i++)
                 orbx_launch_resize(sp[i].lv[l - 1], sp[i].lv[l], h->tabs[l], h->area2[l], f0[i + 1] - f0[i], l == 1 ? src_end : nullptr, st[i]);
-        if (prof) HIPCHK(hipEventRecord(h->ev[1], s));
+        if (pe) HIPCHK(hipEventRecord(pe[1], s));
         for (int i = 0; i < nsub; i++) orbx_launch_fast(sp[i], sw[i], f0[i + 1] - f0[i], 0, P.ncells, st[i]);
     }
-    if (prof) HIPCHK(hipEventRecord(h->ev[2], s));
+    if (pe) HIPCHK(hipEventRecord(pe[2], s));
     for (int i = 0; i < nsub; i++) orbx_launch_octree(sp[i], sw[i], f0[i + 1] - f0[i], h->oct_lds, st[i]);
-    if (prof) HIPCHK(hipEventRecord(h->ev[3], s));
+    if (pe) HIPCHK(hipEventRecord(pe[3], s));
     for (int i = 0; i < nsub; i++)
         orbx_launch_describe(sp[i], sw[i], f0[i + 1] - f0[i], d_kps + (long long)f0[i] * P.out_cap,
                              d_desc + (long long)f0[i] * P.out_cap * 32, d_counts + f0[i], d_status + f0[i], st[i]);
-    if (prof) HIPCHK(hipEventRecord(h->ev[4], s));
+    if (pe) HIPCHK(hipEventRecord(pe[4], s));
     for (int i = 1; i < nsub; i++) {
         HIPCHK(hipEventRecord(h->ev_join[i - 1], st[i]));
         HIPCHK(hipStreamWaitEvent(s, h->ev_join[i - 1], 0));
     }
     HIPCHK(hipGetLastError());
+    if (h->profiling == 2) h->ring_calls++;
     guard.ok = true;
     return ORBX_OK;
 }
 
 static int finish_profile(orbx_extractor *h)
 {
-    if (!h->profiling) return ORBX_OK;
+    if (h->profiling != 1) return ORBX_OK;
     HIPCHK(hipEventSynchronize(h->ev[4]));
     for (int i = 0; i < 4; i++) HIPCHK(hipEventElapsedTime(&h->stage_ms[i], h->ev[i], h->ev[i + 1]));
     return ORBX_OK;
@@ -485,7 +510,7 @@ extern "C" int orbx_extract_batch_device(orbx_extractor *h, const uint8_t *d_ima
     int rc = enqueue(h, d_images, nframes, width, height, row_stride, (long long)frame_stride, d_keypoints,
                      d_descriptors, d_counts, d_status, s);
     if (rc != ORBX_OK) return rc;
-    if (h->profiling) return finish_profile(h);
+    if (h->profiling == 1) return finish_profile(h);
     return ORBX_OK;
 }
 

@@ -212,3 +212,24 @@ def test_pyramid_border_download(orbx, synth):
     opyr = O.Extractor(300).pyramid(img)
     for l in range(8):
         assert np.array_equal(pyr[l], np.pad(opyr[l], 19, mode="reflect"))     # copyMakeBorder REFLECT_101
+
+
+def test_ring_profiling_mode(orbx, synth):
+    """orbx_set_profiling(2): stage events dropped into the caller's stream, read back after the caller synchronises."""
+    import torch
+    W, H, B = 320, 240, 2
+    fr = torch.from_numpy(synth.stream(3, W, H, B)).cuda()
+    ex = orbx.ORBextractor(300, max_width=W, max_height=H, max_batch=B)
+    cap = ex.cap
+    k = torch.zeros((B, cap, 7), device="cuda"); d = torch.zeros((B, cap, 32), dtype=torch.uint8, device="cuda")
+    c = torch.zeros(B, dtype=torch.int32, device="cuda"); s = torch.zeros(B, dtype=torch.int32, device="cuda")
+    st = torch.cuda.Stream()
+    ex.set_profiling(2)
+    for _ in range(20):                       # more calls than the ring holds
+        ex.extract_batch_device(fr.data_ptr(), B, W, H, fr.stride(1), fr.stride(0), k.data_ptr(), d.data_ptr(), c.data_ptr(), s.data_ptr(), st.cuda_stream)
+    st.synchronize()
+    ms = ex.stage_ms_ring(16)
+    assert ms.shape == (16, 4) and (ms > 0).all() and (ms < 50).all()
+    ex.set_profiling(0)
+    ref = ex(synth.stream(3, W, H, B)[0])
+    assert int(c[0]) == len(ref[0])
