@@ -191,6 +191,7 @@ def main():
     ap.add_argument("--no-match", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-pipelined", action="store_true", help="skip the extra two-stream / HIP-graph throughput pass")
+    ap.add_argument("--pipelined-streams", type=int, default=2)
     ap.add_argument("--cpu-budget", type=float, default=12.0)
     args = ap.parse_args()
 
@@ -382,7 +383,7 @@ def main():
     pipelined = None
     if rank == 0 and world == 1 and not args.no_pipelined:
         try:
-            pipelined = pipelined_pass(pkg, torch, frames, W, H, B, NF, local, do_match, args.steps, nk_local)
+            pipelined = pipelined_pass(pkg, torch, frames, W, H, B, NF, local, do_match, args.steps, nk_local, args.pipelined_streams)
         except Exception as e:
             pipelined = {"error": str(e)[:200]}
 
