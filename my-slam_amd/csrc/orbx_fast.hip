@@ -165,8 +165,11 @@ __global__ __launch_bounds__(FAST_THREADS) void k_fast_cells(OrbxPlan plan, Orbx
     // lb / wg_per_frame without the integer-division expansion: multiply by floor(2^32 / d) + 1, one correction step
     int f = wg_rcp ? (int)__umulhi((uint32_t)lb, wg_rcp) : lb;   // wg_rcp == 0: one workgroup per frame
     f -= (f * wg_per_frame > lb) ? 1 : 0;
-    const int cell = cell_lo + (lb - f * wg_per_frame) * (FAST_THREADS / 64) + wave;
-    if (cell >= cell_hi) return;
+    // A frame's cells are taken last level first: the cells of the small levels are the slow ones (corner-dense, often
+    // both threshold passes), and a kernel that ends on them drains with most of the GPU idle.  Ending on the uniform
+    // level-0 cells took 7 % off the launch.
+    const int cell = cell_hi - 1 - ((lb - f * wg_per_frame) * (FAST_THREADS / 64) + wave);
+    if (cell < cell_lo) return;
     FastLds<TS, TH, ZS> &S = lds[wave];
     FT_DECL;
 
