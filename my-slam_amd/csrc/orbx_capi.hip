@@ -63,6 +63,7 @@ struct orbx_extractor {
     orbx_keypoint *d_kps = nullptr; uint8_t *d_desc = nullptr; int32_t *d_counts = nullptr, *d_status = nullptr;
     uint8_t *h_in = nullptr;
     orbx_keypoint *h_kps = nullptr; uint8_t *h_desc = nullptr; int32_t *h_counts = nullptr, *h_status = nullptr;
+    uint8_t *d_out = nullptr, *h_out = nullptr; size_t out_hdr = 0, out_kps_bytes = 0, out_bytes = 0;   // the block the eight pointers above point into
     int profiling = 0; hipEvent_t ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr}; float stage_ms[4] = {0, 0, 0, 0};
     // profiling == 2: the stage events of the last ORBX_PROF_RING calls are recorded and never waited for by the library
     hipEvent_t evr[ORBX_PROF_RING][5] = {}; long long ring_calls = 0;
@@ -189,8 +190,8 @@ static void free_all(orbx_extractor *h)
     hipFree(h->d_input); hipFree(h->d_pyr); hipFree(h->d_tab_i); hipFree(h->d_tab_s); hipFree(h->d_cells);
     hipFree(h->work.cand); hipFree(h->work.cand_count); hipFree(h->work.owner); hipFree(h->work.arena);
     hipFree(h->work.sel); hipFree(h->work.nk); hipFree(h->work.ncand); hipFree(h->work.errflags);
-    hipFree(h->d_kps); hipFree(h->d_desc); hipFree(h->d_counts); hipFree(h->d_status);
-    hipHostFree(h->h_in); hipHostFree(h->h_kps); hipHostFree(h->h_desc); hipHostFree(h->h_counts); hipHostFree(h->h_status);
+    hipFree(h->d_out);
+    hipHostFree(h->h_in); hipHostFree(h->h_out);
     for (auto &e : h->ev) if (e) hipEventDestroy(e);
     for (auto &set : h->evr) for (auto &e : set) if (e) hipEventDestroy(e);
     for (auto &e : h->ev_join) if (e) hipEventDestroy(e);
@@ -261,19 +262,22 @@ extern "C" int orbx_create(orbx_extractor **out, int nfeatures, float scale_fact
     ALLOC(h->work.nk, B * ORBX_MAX_LEVELS * sizeof(uint32_t));
     ALLOC(h->work.ncand, B * ORBX_MAX_LEVELS * sizeof(uint32_t));
     ALLOC(h->work.errflags, B * sizeof(uint32_t));
-    ALLOC(h->d_kps, B * M.out_cap * sizeof(orbx_keypoint));
-    ALLOC(h->d_desc, B * M.out_cap * 32);
-    ALLOC(h->d_counts, B * sizeof(int32_t));
-    ALLOC(h->d_status, B * sizeof(int32_t));
+    // the host-buffer entry points' staging outputs live in ONE block, [counts B | status B | keypoints B x cap | descriptors
+    // B x cap x 32], mirrored in pinned memory: a full batch (or a max_batch = 1 handle) comes back with a single copy
+    h->out_hdr = align_up(2 * B * sizeof(int32_t), 256);
+    h->out_kps_bytes = B * M.out_cap * sizeof(orbx_keypoint);
+    h->out_bytes = h->out_hdr + h->out_kps_bytes + B * M.out_cap * 32;
+    ALLOC(h->d_out, h->out_bytes);
 #undef ALLOC
     if (hipHostMalloc((void **)&h->h_in, B * h->in_frame + 256) != hipSuccess ||
-        hipHostMalloc((void **)&h->h_kps, B * M.out_cap * sizeof(orbx_keypoint)) != hipSuccess ||
-        hipHostMalloc((void **)&h->h_desc, B * M.out_cap * 32) != hipSuccess ||
-        hipHostMalloc((void **)&h->h_counts, B * sizeof(int32_t)) != hipSuccess ||
-        hipHostMalloc((void **)&h->h_status, B * sizeof(int32_t)) != hipSuccess) {
+        hipHostMalloc((void **)&h->h_out, h->out_bytes) != hipSuccess) {
         free_all(h);
         return fail(ORBX_E_HIP, "hipHostMalloc failed");
     }
+    h->d_counts = reinterpret_cast<int32_t *>(h->d_out); h->d_status = h->d_counts + B;
+    h->d_kps = reinterpret_cast<orbx_keypoint *>(h->d_out + h->out_hdr); h->d_desc = h->d_out + h->out_hdr + h->out_kps_bytes;
+    h->h_counts = reinterpret_cast<int32_t *>(h->h_out); h->h_status = h->h_counts + B;
+    h->h_kps = reinterpret_cast<orbx_keypoint *>(h->h_out + h->out_hdr); h->h_desc = h->h_out + h->out_hdr + h->out_kps_bytes;
     if (hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess) { free_all(h); return fail(ORBX_E_HIP, "hipStreamCreate failed"); }
     for (auto &e : h->ev) if (hipEventCreate(&e) != hipSuccess) { free_all(h); return fail(ORBX_E_HIP, "hipEventCreate failed"); }
     for (auto &a : h->aux) if (hipStreamCreateWithFlags(&a, hipStreamNonBlocking) != hipSuccess) { free_all(h); return fail(ORBX_E_HIP, "hipStreamCreate failed"); }
@@ -542,10 +546,13 @@ extern "C" int orbx_extract_batch(orbx_extractor *h, const uint8_t *images, int 
     int rc = enqueue(h, h->d_input, nframes, width, height, h->in_stride, (long long)h->in_frame, h->d_kps, h->d_desc,
                      h->d_counts, h->d_status, s);
     if (rc != ORBX_OK) return rc;
-    HIPCHK(hipMemcpyAsync(h->h_counts, h->d_counts, sizeof(int32_t) * nframes, hipMemcpyDeviceToHost, s));
-    HIPCHK(hipMemcpyAsync(h->h_status, h->d_status, sizeof(int32_t) * nframes, hipMemcpyDeviceToHost, s));
-    HIPCHK(hipMemcpyAsync(h->h_kps, h->d_kps, sizeof(orbx_keypoint) * (size_t)ocap * nframes, hipMemcpyDeviceToHost, s));
-    HIPCHK(hipMemcpyAsync(h->h_desc, h->d_desc, (size_t)32 * ocap * nframes, hipMemcpyDeviceToHost, s));
+    if (nframes == h->max_batch) {
+        HIPCHK(hipMemcpyAsync(h->h_out, h->d_out, h->out_bytes, hipMemcpyDeviceToHost, s));
+    } else {
+        HIPCHK(hipMemcpyAsync(h->h_out, h->d_out, h->out_hdr, hipMemcpyDeviceToHost, s));
+        HIPCHK(hipMemcpyAsync(h->h_kps, h->d_kps, sizeof(orbx_keypoint) * (size_t)ocap * nframes, hipMemcpyDeviceToHost, s));
+        HIPCHK(hipMemcpyAsync(h->h_desc, h->d_desc, (size_t)32 * ocap * nframes, hipMemcpyDeviceToHost, s));
+    }
     HIPCHK(hipStreamSynchronize(s));
     rc = finish_profile(h);
     if (rc != ORBX_OK) return rc;
