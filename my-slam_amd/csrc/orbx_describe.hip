@@ -272,28 +272,38 @@ __global__ __launch_bounds__(256) void k_describe(
     const int x0 = x - 21, y0 = y - 21;
     const int row_bytes = (l == 0) ? L.w : L.stride;   // bytes of a row that may be touched
     const bool fast = (x0 >= 0) && (y0 >= 0) && (y + 21 < L.h) && (x + 21 < L.w) &&   // no reflection needed
-                      (x + 27 < row_bytes) &&                                          // dword over-read stays in the row
-                      (l != 0 || l0_aligned);
+                      (x + 27 < row_bytes);                                            // dword over-read stays in the row
     if (fast) {
-        const int xo = x0 & 3;
         const int rr = lane / 12, d = lane - rr * 12;     // 5 rows per pass, 12 dwords per row
-        // byte offsets inside one frame fit 31 bits; one 24-bit multiply per lane, the row steps are scalar
-        const uint8_t *src = img + (__mul24(y0 + rr, L.stride) + (x0 & ~3) + 4 * d);
         const int step5 = 5 * L.stride;
-        uint32_t gv[9];
+        uint32_t gv[9], xo[9];
+        if (l != 0 || l0_aligned) {   // rows start on a dword: one shift for the whole tile
+            // byte offsets inside one frame fit 31 bits; one 24-bit multiply per lane, the row steps are scalar
+            const uint8_t *src = img + (__mul24(y0 + rr, L.stride) + (x0 & ~3) + 4 * d);
 #pragma unroll
-        for (int p = 0; p < 9; p++) {
-            const int r = p * 5 + rr;
-            gv[p] = (lane < 60 && r < 43) ? *reinterpret_cast<const uint32_t *>(src + p * step5) : 0u;
+            for (int p = 0; p < 9; p++) {
+                const int r = p * 5 + rr;
+                xo[p] = (uint32_t)x0 & 3u;
+                gv[p] = (lane < 60 && r < 43) ? *reinterpret_cast<const uint32_t *>(src + p * step5) : 0u;
+            }
+        } else {                      // caller-owned level 0 with an odd pitch: the shift differs from row to row
+            const uintptr_t b0 = reinterpret_cast<uintptr_t>(img + (__mul24(y0 + rr, L.stride) + x0));
+#pragma unroll
+            for (int p = 0; p < 9; p++) {
+                const int r = p * 5 + rr;
+                const uintptr_t pa = b0 + (uintptr_t)(p * step5);
+                xo[p] = (uint32_t)pa & 3u;
+                gv[p] = (lane < 60 && r < 43) ? reinterpret_cast<const uint32_t *>(pa & ~(uintptr_t)3)[d] : 0u;
+            }
         }
 #pragma unroll
         for (int p = 0; p < 9; p++) {
             const uint32_t hi = __shfl_down(gv[p], 1);
-            const uint32_t v = __builtin_amdgcn_alignbyte(hi, gv[p], (uint32_t)xo);
+            const uint32_t v = __builtin_amdgcn_alignbyte(hi, gv[p], xo[p]);
             const int r = p * 5 + rr;
             if (lane < 60 && r < 43 && d < 11) *reinterpret_cast<uint32_t *>(&S.raw[r * DW_RAW_STRIDE + 4 * d]) = v;
         }
-    } else {   // tile crosses the image border (reflect-101) or unaligned level 0: byte path
+    } else {   // tile crosses the image border (reflect-101): byte path
         for (int i = lane; i < DESC_RAW * DESC_RAW; i += 64) {
             const int r = i / DESC_RAW, c = i - r * DESC_RAW;
             const int gy = reflect101(y0 + r, L.h), gx = reflect101(x0 + c, L.w);

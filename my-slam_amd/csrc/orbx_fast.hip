@@ -191,25 +191,36 @@ __global__ __launch_bounds__(FAST_THREADS) void k_fast_cells(OrbxPlan plan, Orbx
     // memory: zone column 0 (tile column 3) then starts a dword, a zone row is exactly ceil(zw / 4) stage-1 groups
     // (8 for the usual 31..32-px cells instead of 9..10) and no group hangs over the left edge.  The re-alignment is
     // one v_alignbyte_b32 per dword moved.
-    const bool bytes_only = (l == 0 && !l0_aligned);
-    if (bytes_only) {
-        for (int i = lane; i < tw * th; i += 64) {
-            const int y = i / tw, x = i - y * tw;
-            S.tile[y * TS + FAST_PADL + 1 + x] = img[(long long)y * L.stride + iniX + x];
-        }
-    } else {
+    // Rows of levels >= 1 (and of level 0 when the caller's base and strides are multiples of 4) start on a dword, so the
+    // byte shift is the same for every row; a level 0 with an odd pitch (e.g. 1241-px rows handed over as they are) gets
+    // its shift per row.  Either way whole dwords move; the over-read of <= 7 bytes stays inside the image row (>= 10 bytes
+    // follow a tile).
+    {
         constexpr int NDW = (TH + 7) / 4, RPP = 64 / NDW;   // payload dwords per tile row (LDS dwords 1 .. NDW), rows per pass
         static_assert(TS % 4 == 0 && TS >= 4 + 4 * NDW, "tile row too short");
         const int ndw = (tw + 4) >> 2;                    // LDS dwords 1 .. ndw hold tile columns -1 .. tw-1
-        static_assert(NDW == 12 || NDW == 18, "lane / NDW below is written for these");
-        const int r_in = NDW == 12 ? (int)(__umul24((uint32_t)lane, 43u) >> 9) : (int)(__umul24((uint32_t)lane, 57u) >> 10);   // lane / NDW, lane < 64
+        static_assert(NDW == 12 || NDW == 13 || NDW == 18, "lane / NDW below is written for these");
+        const int r_in = NDW == 12 ? (int)(__umul24((uint32_t)lane, 43u) >> 9)
+                       : NDW == 13 ? (int)(__umul24((uint32_t)lane, 79u) >> 10)
+                                   : (int)(__umul24((uint32_t)lane, 57u) >> 10);   // lane / NDW, lane < 64
         const int cdw = lane - r_in * NDW;
-        const uint32_t sh = (uint32_t)(iniX - 1) & 3u;
-        const uint8_t *src = img + ((iniX - 1) & ~3) + 4 * cdw;   // the over-read of 4 bytes stays inside the image row (>= 10 bytes follow a tile)
-        if (r_in < RPP && cdw < ndw) {
-            for (int r = r_in; r < th; r += RPP) {
-                const uint32_t *g2 = reinterpret_cast<const uint32_t *>(src + (long long)r * L.stride);
-                *reinterpret_cast<uint32_t *>(&S.tile[r * TS + FAST_PADL + 4 * cdw]) = __builtin_amdgcn_alignbyte(g2[1], g2[0], sh);
+        if (l == 0 && !l0_aligned) {
+            const uint8_t *src = img + (iniX - 1) + 4 * cdw;
+            if (r_in < RPP && cdw < ndw) {
+                for (int r = r_in; r < th; r += RPP) {
+                    const uintptr_t pa = reinterpret_cast<uintptr_t>(src + (long long)r * L.stride);
+                    const uint32_t *g2 = reinterpret_cast<const uint32_t *>(pa & ~(uintptr_t)3);
+                    *reinterpret_cast<uint32_t *>(&S.tile[r * TS + FAST_PADL + 4 * cdw]) = __builtin_amdgcn_alignbyte(g2[1], g2[0], (uint32_t)pa & 3u);
+                }
+            }
+        } else {
+            const uint32_t sh = (uint32_t)(iniX - 1) & 3u;
+            const uint8_t *src = img + ((iniX - 1) & ~3) + 4 * cdw;
+            if (r_in < RPP && cdw < ndw) {
+                for (int r = r_in; r < th; r += RPP) {
+                    const uint32_t *g2 = reinterpret_cast<const uint32_t *>(src + (long long)r * L.stride);
+                    *reinterpret_cast<uint32_t *>(&S.tile[r * TS + FAST_PADL + 4 * cdw]) = __builtin_amdgcn_alignbyte(g2[1], g2[0], sh);
+                }
             }
         }
     }
@@ -434,6 +445,9 @@ void orbx_launch_fast(const OrbxPlan &plan, const OrbxWork &wk, int nframes, int
     dim3 grid((nwg + 7) & ~7);
     if (maxcell <= 38)   // tile <= 44x44, zone <= 38x38; row = 4 pad + 1 + 44 + over-read (3) -> 52 B
         hipLaunchKernelGGL((k_fast_cells<52, 44, 40>), grid, dim3(FAST_THREADS), 0, s, plan, wk, l0_aligned, cell_lo, cell_hi, wg_per_frame, nwg, wg_per_frame > 1 ? (uint32_t)((1ull << 32) / (unsigned)wg_per_frame + 1) : 0u);
+    else if (maxcell <= 42)   // a level whose detection zone is 90..120 px in one direction has cells of 39..42 (e.g. the flat upper
+                              // levels of 1241x376): tile <= 48x48, 23.4 KB of LDS per workgroup instead of the 42 KB below
+        hipLaunchKernelGGL((k_fast_cells<56, 48, 44>), grid, dim3(FAST_THREADS), 0, s, plan, wk, l0_aligned, cell_lo, cell_hi, wg_per_frame, nwg, wg_per_frame > 1 ? (uint32_t)((1ull << 32) / (unsigned)wg_per_frame + 1) : 0u);
     else                 // cells of tiny levels: tile <= 66x66, zone <= 60x60
         hipLaunchKernelGGL((k_fast_cells<80, 66, 64>), grid, dim3(FAST_THREADS), 0, s, plan, wk, l0_aligned, cell_lo, cell_hi, wg_per_frame, nwg, wg_per_frame > 1 ? (uint32_t)((1ull << 32) / (unsigned)wg_per_frame + 1) : 0u);
 }
