@@ -49,7 +49,7 @@ int main(int argc, char **argv)
     std::vector<int32_t> word(cap), node(cap), bow_ids(cap), match_f(cap), bi(cap), bd(cap), sd(cap), m12(cap), mn(cap), mx(cap);
     std::vector<double> weight(cap), bow_vals(cap);
     std::vector<float> qx(cap), qy(cap), qr(cap), aq(cap), at(cap);
-    double t_stage[5] = {0, 0, 0, 0, 0};
+    std::vector<double> t_stage[5];     // per-stage samples; medians are reported (one slow frame must not skew a stage)
     std::vector<double> t_all;
     long nm_bow = 0, nm_proj = 0;
     for (int k = 0; k < K; k++) {
@@ -85,7 +85,7 @@ int main(int argc, char **argv)
             const double t5 = now_ms();
             if (k >= 5) {
                 const double d[5] = {t1 - t0, t2 - t1, t3 - t2, t4 - t3, t5 - t4};
-                for (int i = 0; i < 5; i++) t_stage[i] += d[i];
+                for (int i = 0; i < 5; i++) t_stage[i].push_back(d[i]);
                 t_all.push_back(t5 - t0);
             }
         }
@@ -93,11 +93,12 @@ int main(int argc, char **argv)
     }
     std::sort(t_all.begin(), t_all.end());
     const double med = t_all.empty() ? 0 : t_all[t_all.size() / 2];
-    const double n = t_all.empty() ? 1 : (double)t_all.size();
+    double sm[5];
+    for (int i = 0; i < 5; i++) { std::sort(t_stage[i].begin(), t_stage[i].end()); sm[i] = t_stage[i].empty() ? 0 : t_stage[i][t_stage[i].size() / 2]; }
     printf("{\"harness\": \"C++ through the C ABI\", \"shape\": \"%dx%d n=%d\", \"frames_timed\": %d, \"ms_per_frame_median\": %.3f, \"frames_per_s\": %.1f, "
-           "\"ms\": {\"extract\": %.3f, \"grid\": %.3f, \"bow\": %.3f, \"search_by_bow\": %.3f, \"search_by_projection\": %.3f}, "
+           "\"ms_median\": {\"extract\": %.3f, \"grid\": %.3f, \"bow\": %.3f, \"search_by_bow\": %.3f, \"search_by_projection\": %.3f}, "
            "\"matches_per_frame\": {\"bow\": %.1f, \"projection\": %.1f}}\n",
-           W, H, NF, (int)t_all.size(), med, med > 0 ? 1000.0 / med : 0.0, t_stage[0] / n, t_stage[1] / n, t_stage[2] / n, t_stage[3] / n, t_stage[4] / n,
+           W, H, NF, (int)t_all.size(), med, med > 0 ? 1000.0 / med : 0.0, sm[0], sm[1], sm[2], sm[3], sm[4],
            (double)nm_bow / std::max(K - 1, 1), (double)nm_proj / std::max(K - 1, 1));
     orbv_destroy(voc); orbm_destroy(mt); orbx_destroy(ex);
     return 0;
