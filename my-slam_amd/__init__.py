@@ -90,6 +90,7 @@ def lib():
         getattr(L, name).restype = C.c_int
     _bind_matcher(L)
     _bind_voc(L)
+    _bind_pose(L)
     _lib = L
     return L
 
@@ -109,6 +110,32 @@ def _bind_voc(L):
     L.orbv_score_l1.restype = C.c_double
     L.orbv_last_error.restype = C.c_char_p
     for name in ("orbv_load_text", "orbv_info", "orbv_transform_features", "orbv_bow_vector", "orbv_feature_vector"):
+        getattr(L, name).restype = C.c_int
+
+
+RAND_FN = C.CFUNCTYPE(C.c_int, C.c_void_p)
+
+
+def _bind_pose(L):
+    vp, ip = C.c_void_p, C.POINTER(C.c_int)
+    if not hasattr(L, "orbp_pnp_create"):
+        return
+    L.orbp_pnp_create.argtypes = [C.POINTER(vp), C.c_int, vp, vp, vp, C.c_float, C.c_float, C.c_float, C.c_float]
+    L.orbp_pnp_destroy.argtypes = [vp]
+    L.orbp_pnp_destroy.restype = None
+    L.orbp_pnp_set_rand.argtypes = [vp, RAND_FN, vp, C.c_int]
+    L.orbp_pnp_set_rand.restype = None
+    L.orbp_pnp_set_ransac_parameters.argtypes = [vp, C.c_double, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float]
+    L.orbp_pnp_get_ransac_state.argtypes = [vp, ip, ip, C.POINTER(C.c_float), ip]
+    L.orbp_pnp_get_ransac_state.restype = None
+    L.orbp_pnp_iterate.argtypes = [vp, C.c_int, ip, vp, ip, vp]
+    L.orbp_pnp_find.argtypes = [vp, vp, ip, vp]
+    L.orbp_epnp.argtypes = [C.c_int, vp, vp, C.c_double, C.c_double, C.c_double, C.c_double, vp, vp]
+    L.orbp_epnp.restype = C.c_double
+    L.orbp_pose_optimization.argtypes = [C.c_int, vp, vp, vp, vp, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, vp, vp]
+    L.orbp_last_error.restype = C.c_char_p
+    for name in ("orbp_pnp_create", "orbp_pnp_set_ransac_parameters", "orbp_pnp_iterate", "orbp_pnp_find",
+                 "orbp_pose_optimization"):
         getattr(L, name).restype = C.c_int
 
 
@@ -463,3 +490,85 @@ class ORBVocabulary:
 
     def score(self, bow1, bow2):
         return self.L.orbv_score_l1(_p(bow1[0]), _p(bow1[1]), len(bow1[0]), _p(bow2[0]), _p(bow2[1]), len(bow2[0]))
+
+
+def _pchk(rc):
+    if rc < 0:
+        raise OrbxError(rc, lib().orbp_last_error().decode())
+    return rc
+
+
+class PnPsolver:
+    """Mirror of ORB_SLAM2::PnPsolver (include/PnPsolver.h:66-78, src/PnPsolver.cc:66-344) over orbp_pnp_*: host-side
+    EPnP RANSAC.  The Frame / MapPoint arguments of the reference constructor become the arrays it reads from them:
+    p2d = mvKeysUn[i].pt, sigma2 = mvLevelSigma2[octave], p3d = GetWorldPos() of the non-bad matches."""
+
+    def __init__(self, p2d, sigma2, p3d, fx, fy, cx, cy, rand=None, rand_max=None):
+        self.L = lib()
+        self.p2d = np.ascontiguousarray(p2d, np.float32).reshape(-1, 2)
+        self.sigma2 = np.ascontiguousarray(sigma2, np.float32)
+        self.p3d = np.ascontiguousarray(p3d, np.float32).reshape(-1, 3)
+        self.N = len(self.p2d)
+        self.h = C.c_void_p()
+        _pchk(self.L.orbp_pnp_create(C.byref(self.h), self.N, _p(self.p2d), _p(self.sigma2), _p(self.p3d), fx, fy, cx, cy))
+        self._cb = None
+        if rand is not None:
+            self._cb = RAND_FN(lambda ctx: int(rand()))
+            self.L.orbp_pnp_set_rand(self.h, self._cb, None, int(rand_max))
+
+    def close(self):
+        if self.h:
+            self.L.orbp_pnp_destroy(self.h)
+            self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def SetRansacParameters(self, probability=0.99, minInliers=8, maxIterations=300, minSet=4, epsilon=0.4, th2=5.991):
+        _pchk(self.L.orbp_pnp_set_ransac_parameters(self.h, probability, minInliers, maxIterations, minSet, epsilon, th2))
+
+    def ransac_state(self):
+        mi, mx, it, ep = C.c_int(), C.c_int(), C.c_int(), C.c_float()
+        self.L.orbp_pnp_get_ransac_state(self.h, C.byref(mi), C.byref(mx), C.byref(ep), C.byref(it))
+        return {"min_inliers": mi.value, "max_its": mx.value, "epsilon": ep.value, "iterations": it.value}
+
+    def iterate(self, nIterations):
+        """-> (Tcw 4x4 float32 or None, bNoMore, vbInliers (bool[N]) or None, nInliers)"""
+        no_more, ninl = C.c_int(), C.c_int()
+        inl = np.zeros(max(self.N, 1), np.uint8)
+        T = np.zeros(16, np.float32)
+        got = _pchk(self.L.orbp_pnp_iterate(self.h, nIterations, C.byref(no_more), _p(inl), C.byref(ninl), _p(T)))
+        if not got:
+            return None, bool(no_more.value), None, 0
+        return T.reshape(4, 4), bool(no_more.value), inl[:self.N].astype(bool), ninl.value
+
+    def find(self):
+        st = self.ransac_state()
+        T, _, inl, n = self.iterate(st["max_its"])
+        return T, inl, n
+
+
+def epnp(pws, us, fu, fv, uc, vc):
+    """PnPsolver::compute_pose (src/PnPsolver.cc:458-508) on all given correspondences -> (R, t, mean reprojection error)."""
+    pws = np.ascontiguousarray(pws, np.float64).reshape(-1, 3)
+    us = np.ascontiguousarray(us, np.float64).reshape(-1, 2)
+    R, t = np.zeros((3, 3)), np.zeros(3)
+    err = lib().orbp_epnp(len(pws), _p(pws), _p(us), fu, fv, uc, vc, _p(R), _p(t))
+    if err < 0:
+        raise OrbxError(ORBX_E_INVALID, lib().orbp_last_error().decode())
+    return R, t, err
+
+
+def PoseOptimization(obs, inv_sigma2, xw, fx, fy, cx, cy, Tcw, u_right=None, bf=0.0):
+    """Optimizer::PoseOptimization (src/Optimizer.cc:239-451) -> (Tcw 4x4 float32, mvbOutlier bool[n], n_inliers)."""
+    obs = np.ascontiguousarray(obs, np.float32).reshape(-1, 2)
+    inv_sigma2 = np.ascontiguousarray(inv_sigma2, np.float32)
+    xw = np.ascontiguousarray(xw, np.float32).reshape(-1, 3)
+    ur = None if u_right is None else np.ascontiguousarray(u_right, np.float32)
+    T = np.ascontiguousarray(Tcw, np.float32).reshape(16).copy()
+    out = np.zeros(max(len(obs), 1), np.uint8)
+    n = _pchk(lib().orbp_pose_optimization(len(obs), _p(obs), _p(ur), _p(inv_sigma2), _p(xw), fx, fy, cx, cy, bf, _p(T), _p(out)))
+    return T.reshape(4, 4), out[:len(obs)].astype(bool), n

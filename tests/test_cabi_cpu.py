@@ -18,7 +18,7 @@ def _declared_symbols():
     names = set()
     for h in glob.glob(os.path.join(ROOT, "include", "*.h")):
         text = re.sub(r"/\*.*?\*/", "", open(h).read(), flags=re.S)
-        names |= set(re.findall(r"\b(orb[xmv]_[a-z0-9_]+)\s*\(", text))
+        names |= set(re.findall(r"\b(orb[xmvp]_[a-z0-9_]+)\s*\(", text))
     return names
 
 
