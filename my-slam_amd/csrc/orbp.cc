@@ -732,6 +732,7 @@ struct Edge {
     int idx; bool stereo;
     double obs[3], xw[3], info;
     double err[3];         // _error: refreshed only where g2o refreshes it
+    double pc[3];          // the point in the camera frame at the estimate compute_error last saw
     bool robust; int level;
 };
 
@@ -744,7 +745,7 @@ struct PoseProblem {
 
     void compute_error(Edge &e) const         // types_six_dof_expmap.h:153-157,184-188; .cpp:290-306
     {
-        double p[3];
+        double *p = e.pc;
         se3_map(est, e.xw, p);
         if (!e.stereo) {
             e.err[0] = e.obs[0] - (p[0] / p[2] * fx + cx);
@@ -777,15 +778,15 @@ struct PoseProblem {
         }
         return sum;
     }
-    void build_system(double H[36], double b[6]) const    // linearizeOplus (.cpp:266-288,335-364) + base_unary_edge.hpp:43-72
+    // linearizeOplus (.cpp:266-288,335-364) + constructQuadraticForm (base_unary_edge.hpp:43-72).  Called right after
+    // compute_active_errors() at the same estimate, so the camera-frame points cached there are the ones g2o maps again.
+    void build_system(double H[36], double b[6]) const
     {
-        for (int i = 0; i < 36; i++) H[i] = 0;
+        double Hu[21] = {0};
         for (int i = 0; i < 6; i++) b[i] = 0;
         for (int k : active) {
             const Edge &e = edges[k];
-            double p[3];
-            se3_map(est, e.xw, p);
-            const double x = p[0], y = p[1], invz = 1.0 / p[2], invz_2 = invz * invz;
+            const double x = e.pc[0], y = e.pc[1], invz = 1.0 / e.pc[2], invz_2 = invz * invz;
             double J[3][6];
             J[0][0] = x * y * invz_2 * fx; J[0][1] = -(1 + (x * x * invz_2)) * fx; J[0][2] = y * invz * fx;
             J[0][3] = -invz * fx; J[0][4] = 0; J[0][5] = x * invz_2 * fx;
@@ -798,17 +799,22 @@ struct PoseProblem {
             }
             double w = 1.0;
             if (e.robust) { double rho[2]; huber(e, chi2(e), rho); w = rho[1]; }
+            const double wi = w * e.info;
+            int u = 0;
             for (int r = 0; r < 6; r++) {
                 double g = 0;
                 for (int d = 0; d < D; d++) g += J[d][r] * e.info * e.err[d];
                 b[r] -= w * g;
-                for (int c = 0; c < 6; c++) {
+                for (int c = r; c < 6; c++, u++) {
                     double h = 0;
-                    for (int d = 0; d < D; d++) h += J[d][r] * (w * e.info) * J[d][c];
-                    H[6 * r + c] += h;
+                    for (int d = 0; d < D; d++) h += J[d][r] * wi * J[d][c];
+                    Hu[u] += h;
                 }
             }
         }
+        int u = 0;
+        for (int r = 0; r < 6; r++)
+            for (int c = r; c < 6; c++, u++) H[6 * r + c] = H[6 * c + r] = Hu[u];
     }
 
     // OptimizationAlgorithmLevenberg::solve driven by SparseOptimizer::optimize (sparse_optimizer.cpp:354-420)

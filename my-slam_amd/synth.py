@@ -90,3 +90,27 @@ def frame_pair(seed, W, H, shift=(7, 3), noise_seed=3, noise=2):
     r = splitmix64(noise_seed, W * H)
     f1 = f1 + (r % np.uint64(2 * noise + 1)).astype(np.int16).reshape(H, W) - noise
     return f0, np.clip(f1, 0, 255).astype(np.uint8)
+
+
+def stream_layers(seed, W, H, nframes, shifts=(1, 2, 3), cell=96, noise_seed0=100, noise=2):
+    """A non-planar scene for the pose solvers: the image plane is tiled with `cell`-px squares, each
+    looking at one of len(shifts) fronto-parallel textured layers; layer r slides shifts[r] px per frame to the left,
+    which is what a camera translating along +x by b per frame sees of a plane at depth fx*b/shifts[r].
+    Returns (frames nframes x H x W uint8, layer H x W uint8 = index into shifts).  Pixels next to a tile edge see a
+    layer change and act as occlusions."""
+    nl = len(shifts)
+    canv = [texture(seed * 16 + r, W + shifts[r] * (nframes - 1), H) for r in range(nl)]
+    gy, gx = np.mgrid[0:H, 0:W]
+    pick = splitmix64(seed + 7777, ((H + cell - 1) // cell) * ((W + cell - 1) // cell))
+    layer = (pick % np.uint64(nl)).astype(np.uint8).reshape((H + cell - 1) // cell, (W + cell - 1) // cell)[gy // cell, gx // cell]
+    out = np.empty((nframes, H, W), dtype=np.uint8)
+    for k in range(nframes):
+        img = np.zeros((H, W), np.int16)
+        for r in range(nl):
+            ox = shifts[r] * k
+            img = np.where(layer == r, canv[r][:, ox:ox + W].astype(np.int16), img)
+        if noise > 0:
+            rr = splitmix64(noise_seed0 + k, W * H)
+            img = img + (rr % np.uint64(2 * noise + 1)).astype(np.int16).reshape(H, W) - noise
+        out[k] = np.clip(img, 0, 255).astype(np.uint8)
+    return out, layer

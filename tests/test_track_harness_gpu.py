@@ -30,3 +30,68 @@ def test_cxx_tracking_harness(orbx, synth, tmp_path):
     # the same SearchByBoW through the Python binding on frames 6 -> 7 agrees with what the harness counted on average
     ex = orbx.ORBextractor(1000, max_width=W, max_height=H)
     assert len(ex(np.fromfile(str(tmp_path / "frames.raw"), np.uint8).reshape(K, H, W)[0])[0]) > 900
+
+
+def test_cxx_tracking_harness_pose_stages(orbx, synth, tmp_path):
+    """BASELINE config 5's whole loop on the three-depth scene: the chained PoseOptimization estimates
+    follow the camera (ground truth: +baseline along x per frame) and EPnP RANSAC relocalises without a prior."""
+    exe = str(tmp_path / "track_harness")
+    subprocess.run(["g++", "-O2", "-std=c++17", "-I", os.path.join(ROOT, "include"), os.path.join(ROOT, "tools/track/track_harness.cc"),
+                    "-L", os.path.join(ROOT, "my-slam_amd/lib"), "-lorbx", "-Wl,-rpath," + os.path.join(ROOT, "my-slam_amd/lib"), "-o", exe],
+                   check=True)
+    W, H, K = 1241, 376, 17
+    frames, layer = synth.stream_layers(5, W, H, K, shifts=(2, 4, 6))
+    frames.tofile(str(tmp_path / "frames.raw"))
+    layer.tofile(str(tmp_path / "layer.raw"))
+    make_vocabulary(str(tmp_path / "voc.txt"), 10, 3, seed=1)
+    out = subprocess.run([exe, str(tmp_path / "frames.raw"), str(W), str(H), str(K), str(tmp_path / "voc.txt"), "2000", "2",
+                          str(tmp_path / "layer.raw"), "0.5", "2", "4", "6"],
+                         check=True, capture_output=True, text=True, timeout=180).stdout
+    lines = [json.loads(l) for l in out.strip().splitlines()]
+    p = lines[-2]["pose"]
+    assert p["inliers_per_frame"] > 100
+    # chained over 16 frames; 1 px of the nearest layer is 1/6 of a baseline
+    assert p["max_translation_error_in_baselines"] < 0.25
+    assert p["relocalizations"] == "2/2" and p["max_reloc_error_in_baselines"] < 0.25
+
+
+def test_pose_from_gpu_matches_python(orbx, synth, tmp_path):
+    """The same chain through the Python mirror: extract (GPU) -> BoW (GPU) -> SearchByBoW -> PnPsolver / PoseOptimization."""
+    W, H, K = 1241, 376, 3
+    fx, fy, cx, cy, base, shifts = 718.856, 718.856, 607.1928, 185.2157, 0.5, (2, 4, 6)
+    frames, layer = synth.stream_layers(5, W, H, K, shifts=shifts)
+    make_vocabulary(str(tmp_path / "voc.txt"), 10, 3, seed=1)
+    voc = orbx.ORBVocabulary(str(tmp_path / "voc.txt"))
+    ex = orbx.ORBextractor(2000, max_width=W, max_height=H)
+    mt = orbx.ORBmatcher(0.7, True, max_queries=4096, max_train=4096, max_pairs=1 << 21)
+    feats = []
+    for k in range(K):
+        kp, de = ex(frames[k])
+        feats.append((kp, de, voc.transform(de, 2)[1]))
+    for k in (1, 2):
+        pk, pd, pfv = feats[k - 1]
+        ck, cd, cfv = feats[k]
+        match_f, nm = mt.SearchByBoW(pk, pd, pfv, ck, cd, cfv)
+        sel = np.flatnonzero(match_f >= 0)
+        assert nm == len(sel) and nm > 150
+        j = match_f[sel]
+        Z = (fx * base / np.array(shifts, np.float64))[layer[np.clip(np.rint(pk["y"][j]).astype(int), 0, H - 1),
+                                                             np.clip(np.rint(pk["x"][j]).astype(int), 0, W - 1)]]
+        xw = np.stack([(pk["x"][j] - cx) * Z / fx + (k - 1) * base, (pk["y"][j] - cy) * Z / fy, Z], 1)     # true previous pose
+        obs = np.stack([ck["x"][sel], ck["y"][sel]], 1)
+        s2 = (np.float32(1.2) ** ck["octave"][sel].astype(np.float32)) ** 2
+        Tprev = np.eye(4, dtype=np.float32)
+        Tprev[0, 3] = -(k - 1) * base
+        T, outl, ninl = orbx.PoseOptimization(obs, 1.0 / s2, xw, fx, fy, cx, cy, Tprev)
+        assert ninl > 100 and abs(T[0, 3] + k * base) < 0.1 * base and abs(T[1, 3]) < 0.1 * base and abs(T[2, 3]) < 0.25 * base
+        assert np.abs(T[:3, :3] - np.eye(3)).max() < 2e-3
+        s = orbx.PnPsolver(obs, s2, xw, fx, fy, cx, cy)
+        s.SetRansacParameters(0.99, 10, 300, 4, 0.5, 5.991)
+        Tr = None
+        for _ in range(100):
+            Tr, no_more, inl, n_in = s.iterate(5)
+            if Tr is not None or no_more:
+                break
+        assert Tr is not None and n_in > 50
+        T2, _, n2 = orbx.PoseOptimization(obs, 1.0 / s2, xw, fx, fy, cx, cy, Tr)
+        assert n2 > 100 and np.abs(T2 - T).max() < 0.1 * base

@@ -1,12 +1,18 @@
-// track_harness.cc -- BASELINE config 5's per-frame loop without the pose solvers, host side in C++ through the C ABI
-// exactly as INTEGRATION.md wires it into the reference:
+// track_harness.cc -- BASELINE config 5's per-frame loop, host side in C++ through the C ABI exactly as INTEGRATION.md
+// wires it into the reference:
 //     Frame::ExtractORB                 -> orbx_extract
 //     Frame::AssignFeaturesToGrid       -> orbm_grid_build
 //     Frame::ComputeBoW                 -> orbv_transform_features + orbv_bow_vector + orbv_feature_vector
 //     Tracking::TrackReferenceKeyFrame  -> orbm_search_by_bow            (ORBmatcher(0.7, true), src/Tracking.cc:774-779)
 //     Tracking::TrackWithMotionModel    -> orbm_search_area_best2 + orbm_rot_filter   (window 15 * scale, octave +-1, TH_HIGH)
-// EPnP RANSAC / g2o pose optimisation (src/PnPsolver.cc, src/Optimizer.cc) are not part of this repository.
-// Inputs: a raw frame file (nframes x H x W bytes) and a vocabulary text file, both written by tools/track/prep_inputs.py.
+//     Optimizer::PoseOptimization       -> orbp_pose_optimization        (src/Tracking.cc:783-787: start from the last pose)
+//     Relocalization's PnPsolver        -> orbp_pnp_* (0.99,10,300,4,0.5,5.991; iterate(5)) + orbp_pose_optimization
+//                                          (src/Tracking.cc:1392-1445), run every 8th frame to time it
+// The pose stages need a scene with depth: prep_inputs.py writes the layered stream of my_slam_amd.synth.stream_layers
+// and its per-pixel layer map; the "MapPoints" of the previous frame are its keypoints back-projected to the depth of
+// their layer through the *estimated* previous pose, so the reported translation error is the drift of the whole chain.
+// Inputs: a raw frame file (nframes x H x W bytes), a vocabulary text file and (optional) the layer map, all written by
+// tools/track/prep_inputs.py.
 // build: g++ -O2 -std=c++17 -I include tools/track/track_harness.cc -L my-slam_amd/lib -lorbx -Wl,-rpath,$PWD/my-slam_amd/lib -o tools/track/track_harness
 #include <algorithm>
 #include <chrono>
@@ -18,6 +24,7 @@
 #include "orbx.h"
 #include "orbm.h"
 #include "orbv.h"
+#include "orbp.h"
 
 static double now_ms() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 #define CHK(e) do { int rc_ = (e); if (rc_ < 0) { fprintf(stderr, "%s failed: %d (%s | %s | %s)\n", #e, rc_, orbx_last_error(), orbm_last_error(), orbv_last_error()); return 2; } } while (0)
@@ -31,9 +38,21 @@ struct FrameData {
 
 int main(int argc, char **argv)
 {
-    if (argc < 7) { fprintf(stderr, "usage: %s frames.raw W H nframes voc.txt nfeatures [levelsup]\n", argv[0]); return 1; }
+    if (argc < 7) { fprintf(stderr, "usage: %s frames.raw W H nframes voc.txt nfeatures [levelsup [layer.raw baseline s0 s1 s2]]\n", argv[0]); return 1; }
     const char *fpath = argv[1]; const int W = atoi(argv[2]), H = atoi(argv[3]), K = atoi(argv[4]);
     const char *vpath = argv[5]; const int NF = atoi(argv[6]); const int levelsup = argc > 7 ? atoi(argv[7]) : 2;
+    const bool pose = argc > 12;
+    const float fx = 718.856f, fy = 718.856f, cx = 607.1928f, cy = 185.2157f;      // Examples/Monocular/KITTI00-02.yaml
+    std::vector<uint8_t> layer;
+    double base = 0, depth[3] = {0, 0, 0};
+    if (pose) {
+        layer.resize((size_t)W * H);
+        FILE *lf = fopen(argv[8], "rb");
+        if (!lf || fread(layer.data(), 1, layer.size(), lf) != layer.size()) { fprintf(stderr, "cannot read %s\n", argv[8]); return 1; }
+        fclose(lf);
+        base = atof(argv[9]);
+        for (int r = 0; r < 3; r++) depth[r] = fx * base / atof(argv[10 + r]);
+    }
     std::vector<uint8_t> frames((size_t)W * H * K);
     FILE *f = fopen(fpath, "rb");
     if (!f || fread(frames.data(), 1, frames.size(), f) != frames.size()) { fprintf(stderr, "cannot read %s\n", fpath); return 1; }
@@ -50,8 +69,12 @@ int main(int argc, char **argv)
     std::vector<double> weight(cap), bow_vals(cap);
     std::vector<float> qx(cap), qy(cap), qr(cap), aq(cap), at(cap);
     std::vector<double> t_stage[5];     // per-stage samples; medians are reported (one slow frame must not skew a stage)
-    std::vector<double> t_all;
-    long nm_bow = 0, nm_proj = 0;
+    std::vector<double> t_all, t_pose, t_reloc;
+    long nm_bow = 0, nm_proj = 0, n_inl = 0, n_reloc = 0, n_reloc_ok = 0;
+    float Tprev[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};       // frame 0 = world
+    std::vector<float> obs(2 * cap), is2(cap), xw(3 * cap), s2(cap);
+    std::vector<uint8_t> outl(cap), inl(cap);
+    double max_err = 0, max_reloc_err = 0;
     for (int k = 0; k < K; k++) {
         cur.kps.resize(cap); cur.desc.resize((size_t)cap * 32);
         cur.fv_node.resize(cap); cur.fv_off.resize(cap + 1); cur.fv_idx.resize(cap);
@@ -72,6 +95,52 @@ int main(int argc, char **argv)
                                    cur.fv_off.data(), cur.fv_idx.data(), cur.fv_n, 0.7f, 1, match_f.data(), &nm));
             nm_bow += nm;
             const double t4 = now_ms();
+            if (pose) {
+                // MapPoints of the previous frame: Xc = K^-1 (u, v, 1) * depth(layer), Xw = Rprev^T (Xc - tprev)
+                int nc = 0;
+                for (int i = 0; i < cur.n; i++) {
+                    const int j = match_f[i];
+                    if (j < 0) continue;
+                    const orbx_keypoint &p = prev.kps[j], &c = cur.kps[i];
+                    const int px = std::min(std::max((int)lrintf(p.x), 0), W - 1), py = std::min(std::max((int)lrintf(p.y), 0), H - 1);
+                    const double Z = depth[layer[(size_t)py * W + px]];
+                    const double Xc[3] = {(p.x - cx) * Z / fx - Tprev[3], (p.y - cy) * Z / fy - Tprev[7], Z - Tprev[11]};
+                    for (int a = 0; a < 3; a++) xw[3 * nc + a] = (float)(Tprev[a] * Xc[0] + Tprev[4 + a] * Xc[1] + Tprev[8 + a] * Xc[2]);
+                    obs[2 * nc] = c.x; obs[2 * nc + 1] = c.y;
+                    const float sig2 = powf(1.2f, (float)c.octave) * powf(1.2f, (float)c.octave);
+                    s2[nc] = sig2; is2[nc] = 1.0f / sig2;
+                    nc++;
+                }
+                float T[16];
+                memcpy(T, Tprev, sizeof T);
+                const double tp0 = now_ms();
+                const int ni = orbp_pose_optimization(nc, obs.data(), nullptr, is2.data(), xw.data(), fx, fy, cx, cy, 0.f, T, outl.data());
+                const double tp1 = now_ms();
+                if (ni < 0) { fprintf(stderr, "pose optimisation failed: %s\n", orbp_last_error()); return 2; }
+                n_inl += ni;
+                if (k >= 5) t_pose.push_back(tp1 - tp0);
+                const double err = std::fabs(T[3] + k * base) + std::fabs(T[7]) + std::fabs(T[11]);
+                max_err = std::max(max_err, err / base);
+                if (k % 8 == 0) {            // relocalisation: no prior, EPnP RANSAC then pose optimisation on its inliers' pose
+                    const double tr0 = now_ms();
+                    orbp_pnp *ps = nullptr;
+                    CHK(orbp_pnp_create(&ps, nc, obs.data(), s2.data(), xw.data(), fx, fy, cx, cy));
+                    CHK(orbp_pnp_set_ransac_parameters(ps, 0.99, 10, 300, 4, 0.5f, 5.991f));
+                    float Tr[16]; int no_more = 0, ninl = 0, got = 0;
+                    while (!got && !no_more) got = orbp_pnp_iterate(ps, 5, &no_more, inl.data(), &ninl, Tr);
+                    orbp_pnp_destroy(ps);
+                    if (got > 0) {
+                        orbp_pose_optimization(nc, obs.data(), nullptr, is2.data(), xw.data(), fx, fy, cx, cy, 0.f, Tr, outl.data());
+                        const double e = (std::fabs(Tr[3] + k * base) + std::fabs(Tr[7]) + std::fabs(Tr[11])) / base;
+                        max_reloc_err = std::max(max_reloc_err, e);
+                        n_reloc_ok++;
+                    }
+                    n_reloc++;
+                    t_reloc.push_back(now_ms() - tr0);
+                }
+                memcpy(Tprev, T, sizeof T);
+            }
+            const double t4b = now_ms();
             for (int i = 0; i < prev.n; i++) {           // motion-model windows around the previous positions
                 const orbx_keypoint &p = prev.kps[i];
                 qx[i] = p.x; qy[i] = p.y; qr[i] = 15.0f * powf(1.2f, (float)p.octave);
@@ -84,7 +153,7 @@ int main(int argc, char **argv)
             nm_proj += orbm_rot_filter(aq.data(), at.data(), m12.data(), prev.n);
             const double t5 = now_ms();
             if (k >= 5) {
-                const double d[5] = {t1 - t0, t2 - t1, t3 - t2, t4 - t3, t5 - t4};
+                const double d[5] = {t1 - t0, t2 - t1, t3 - t2, t4 - t3, t5 - t4b};
                 for (int i = 0; i < 5; i++) t_stage[i].push_back(d[i]);
                 t_all.push_back(t5 - t0);
             }
@@ -95,6 +164,13 @@ int main(int argc, char **argv)
     const double med = t_all.empty() ? 0 : t_all[t_all.size() / 2];
     double sm[5];
     for (int i = 0; i < 5; i++) { std::sort(t_stage[i].begin(), t_stage[i].end()); sm[i] = t_stage[i].empty() ? 0 : t_stage[i][t_stage[i].size() / 2]; }
+    if (pose) {
+        std::sort(t_pose.begin(), t_pose.end()); std::sort(t_reloc.begin(), t_reloc.end());
+        printf("{\"pose\": {\"ms_median_pose_optimization\": %.3f, \"ms_median_relocalization\": %.3f, \"inliers_per_frame\": %.1f, "
+               "\"max_translation_error_in_baselines\": %.4f, \"relocalizations\": \"%ld/%ld\", \"max_reloc_error_in_baselines\": %.4f}}\n",
+               t_pose.empty() ? 0 : t_pose[t_pose.size() / 2], t_reloc.empty() ? 0 : t_reloc[t_reloc.size() / 2],
+               (double)n_inl / std::max(K - 1, 1), max_err, n_reloc_ok, n_reloc, max_reloc_err);
+    }
     printf("{\"harness\": \"C++ through the C ABI\", \"shape\": \"%dx%d n=%d\", \"frames_timed\": %d, \"ms_per_frame_median\": %.3f, \"frames_per_s\": %.1f, "
            "\"ms_median\": {\"extract\": %.3f, \"grid\": %.3f, \"bow\": %.3f, \"search_by_bow\": %.3f, \"search_by_projection\": %.3f}, "
            "\"matches_per_frame\": {\"bow\": %.1f, \"projection\": %.1f}}\n",
