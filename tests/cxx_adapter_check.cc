@@ -6,10 +6,40 @@
 #include <cstring>
 #include "../my-slam_amd/host/ORBextractor.h"
 #include "../my-slam_amd/host/ORBmatcher.h"
+#include "../my-slam_amd/host/PnPsolver.h"
 
 int main(int argc, char **argv)
 {
     if (argc > 1 && !strcmp(argv[1], "compile-only")) return 0;
+    if (argc > 1 && !strcmp(argv[1], "pose")) {
+        // host-only: a camera at t = (0.3, -0.1, 0.2) looking at 60 points, 20 of them mismatched; Relocalization's call
+        // sequence (src/Tracking.cc:1392-1445): PnPsolver -> SetRansacParameters -> iterate(5) -> PoseOptimization
+        const float fx = 718.856f, fy = 718.856f, cx = 607.19f, cy = 185.2f, t[3] = {0.3f, -0.1f, 0.2f};
+        std::vector<float> p2d, s2, p3d, is2;
+        std::vector<size_t> idx;
+        unsigned long long r = 12345;
+        auto u01 = [&]() { r = r * 6364136223846793005ull + 1442695040888963407ull; return (double)(r >> 11) / 9007199254740992.0; };
+        for (int i = 0; i < 60; i++) {
+            const float X = (float)(u01() * 8 - 4), Y = (float)(u01() * 4 - 2), Z = (float)(4 + 16 * u01());
+            float u = fx * (X + t[0]) / (Z + t[2]) + cx, v = fy * (Y + t[1]) / (Z + t[2]) + cy;
+            if (i % 3 == 0) { u += 40; v -= 35; }
+            p3d.insert(p3d.end(), {X, Y, Z}); p2d.insert(p2d.end(), {u, v}); s2.push_back(1.f); is2.push_back(1.f); idx.push_back(2 * i);
+        }
+        srand(1);
+        ORB_SLAM2::PnPsolver solver(p2d, s2, p3d, idx, 120, fx, fy, cx, cy);
+        solver.SetRansacParameters(0.99, 10, 300, 4, 0.5, 5.991);
+        std::vector<bool> inl; int nInl = 0; bool noMore = false;
+        std::optional<ORB_SLAM2::Pose> T;
+        while (!T && !noMore) T = solver.iterate(5, noMore, inl, nInl);
+        if (!T) { printf("no pose\n"); return 1; }
+        std::vector<bool> outl;
+        ORB_SLAM2::Pose Tcw = *T;
+        const int good = ORB_SLAM2::Optimizer::PoseOptimization(p2d, {}, is2, p3d, fx, fy, cx, cy, 0.f, Tcw, outl);
+        int wrongKept = 0;
+        for (int i = 0; i < 60; i += 3) wrongKept += !outl[i];
+        printf("%d %d %d %.4f %.4f %.4f\n", nInl, good, wrongKept, Tcw[3], Tcw[7], Tcw[11]);
+        return 0;
+    }
     if (argc < 4) { fprintf(stderr, "usage: %s raw.u8 W H\n", argv[0]); return 2; }
     const int W = atoi(argv[2]), H = atoi(argv[3]);
     cv::Mat im(H, W, cv::CV_8U);

@@ -23,6 +23,16 @@ def test_adapters_compile_and_link(orbx, tmp_path):
     assert subprocess.run([exe, "compile-only"]).returncode == 0
 
 
+def test_pose_adapters_relocalise(orbx, tmp_path):
+    """host/PnPsolver.h: Relocalization's call sequence on a synthetic scene with a third of the matches wrong (host code,
+    no GPU needed)."""
+    exe = _build(orbx, str(tmp_path / "adapter_check"))
+    out = subprocess.run([exe, "pose"], capture_output=True, text=True, check=True).stdout.split()
+    n_inl, good, wrong_kept = int(out[0]), int(out[1]), int(out[2])
+    assert n_inl >= 38 and good == 40 and wrong_kept == 0
+    assert np.abs(np.array([float(v) for v in out[3:6]]) - [0.3, -0.1, 0.2]).max() < 2e-3
+
+
 @pytest.mark.gpu
 def test_adapter_equals_cabi(orbx, synth, tmp_path):
     exe = _build(orbx, str(tmp_path / "adapter_check"))
