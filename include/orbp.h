@@ -25,8 +25,9 @@
  * Dependencies the reference takes from OpenCV 3.1.0 / Eigen3 (neither is in the image) are replaced by a one-sided
  * Jacobi SVD and a 6x6 LDL^T written here.  Where the reference's result depends on those libraries' internals the
  * behaviour is implementation-defined and documented in DESIGN.md ("parity unpinned"): the basis OpenCV returns for
- * the (numerically) null singular vectors of the rank-8 M^T M of a 4-point sample -- this library takes the
- * eigenvectors, as the EPnP paper defines it -- and the completion of U for a rank-deficient 3x3.
+ * the (numerically) null singular vectors of the rank-8 M^T M of a 4-point sample (any orthonormal basis of that null
+ * space is a valid SVD; which one comes out is an artefact of the Jacobi sweep order, and EPnP's beta linearisations
+ * depend on it), the sign of the PCA axes, and the completion of U for a rank-deficient 3x3.
  * RANSAC draws: DUtils::Random::RandomInt (Thirdparty/DBoW2/DUtils/Random.cpp:47-50) on libc rand(); the default
  * source here is the same rand() with the same formula, so a process that seeds like the reference draws like it.
  */

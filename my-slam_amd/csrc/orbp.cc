@@ -263,8 +263,9 @@ struct Epnp {
         double U[9], W[3], V[9];
         jacobi_svd(abt, 3, 3, U, W, V);
         if (!(W[2] > 2 * DBL_EPSILON * (W[0] + W[1] + W[2]))) {
-            // rank-deficient (coplanar points): complete U to an orthonormal basis.  OpenCV fills the column with a
-            // vector of its own making, so the reference is implementation-defined here.
+            // rank-deficient (coplanar points): complete U to an orthonormal basis.  In OpenCV's Jacobi SVD the third
+            // left vector is what rounding noise leaves after orthogonalisation against the other two, i.e. +-(u1 x u2)
+            // with a sign nobody chose; the reference is implementation-defined here.
             const double a[3] = {U[0], U[3], U[6]}, b[3] = {U[1], U[4], U[7]};
             U[2] = a[1] * b[2] - a[2] * b[1]; U[5] = a[2] * b[0] - a[0] * b[2]; U[8] = a[0] * b[1] - a[1] * b[0];
         }
