@@ -124,10 +124,10 @@ __global__ __launch_bounds__(M_THREADS) void k_best2_dense(
 }
 
 // merge the train-range partials of one query: the two smallest keys of the union
-__device__ __forceinline__ void merge_partials(const uint2 *__restrict__ part, int S, long long stride_z, long long o,
-                                               int &bi, int &bd, int &sd)
+__device__ __forceinline__ void merge_partial_keys(const uint2 *__restrict__ part, int S, long long stride_z, long long o,
+                                                   uint32_t &bk, uint32_t &sk)
 {
-    uint32_t bk = M_KEY_NONE, sk = M_KEY_NONE;
+    bk = M_KEY_NONE; sk = M_KEY_NONE;
     for (int z0 = 0; z0 < S; z0 += 8) {   // eight partials per round trip (a load per iteration would be one memory latency each)
         uint2 p[8];
 #pragma unroll
@@ -138,6 +138,12 @@ __device__ __forceinline__ void merge_partials(const uint2 *__restrict__ part, i
             sk = med3u(bk, sk, p[u].y); bk = min(bk, p[u].y);
         }
     }
+}
+__device__ __forceinline__ void merge_partials(const uint2 *__restrict__ part, int S, long long stride_z, long long o,
+                                               int &bi, int &bd, int &sd)
+{
+    uint32_t bk, sk;
+    merge_partial_keys(part, S, stride_z, o, bk, sk);
     bd = (int)(bk >> 22);
     sd = (int)(sk >> 22);
     bi = bd < 256 ? (int)(bk & 0x3FFFFFu) : -1;
@@ -230,6 +236,19 @@ __global__ __launch_bounds__(M_THREADS) void k_dist_dense(
     const uint4 *Q = reinterpret_cast<const uint4 *>(q) + 2 * (long long)i;
     const uint4 *Tj = reinterpret_cast<const uint4 *>(t) + 2 * (long long)j;
     dist[c] = hamming256(Q[0], Q[1], Tj[0], Tj[1]);
+}
+
+// Many splits (few, large frame pairs): k_accept_rot is one workgroup per pair and would pull S partials per query through
+// one CU.  This grid-wide pre-merge leaves one (best, second) key pair per query, which merges like a single partial.
+__global__ __launch_bounds__(M_THREADS) void k_merge_keys(const uint2 *__restrict__ part, int S, const int32_t *__restrict__ nqv,
+                                                         int cap, uint2 *__restrict__ merged)
+{
+    const int b = blockIdx.y, i = blockIdx.x * M_THREADS + threadIdx.x;
+    if (i >= nqv[b] || i >= cap) return;
+    const long long o = (long long)b * cap + i;
+    uint32_t bk, sk;
+    merge_partial_keys(part, S, (long long)gridDim.y * cap, o, bk, sk);
+    merged[o] = make_uint2(bk, sk);
 }
 
 // ---- acceptance (:228-232) + rotation histogram (:236-246) + ComputeThreeMaxima + cull (:266-284) ----
@@ -420,6 +439,7 @@ static int check_csr(const int32_t *off, const int32_t *idx, int nq, int nt, int
 }
 
 // train-range splits so that the launch has >= ~4 waves per SIMD (1024 SIMDs); <= 64
+#define ORBM_PREMERGE_SPLITS 16
 static int pick_splits(int nq_cap, int nbatch, int nt_hint)
 {
     const long long waves = (long long)nbatch * ((nq_cap + M_THREADS - 1) / M_THREADS) * (M_THREADS / 64);
@@ -518,7 +538,7 @@ static int launch_dense_batch(orbm_matcher *m, const uint8_t *d_q, const int32_t
                               const int32_t *d_nt, int cap, int nbatch, hipStream_t s, int *S_out)
 {
     const int S = pick_splits(cap, nbatch, cap);
-    int rc = ensure_partials(m, (size_t)S * nbatch * cap);
+    int rc = ensure_partials(m, (size_t)(S + 1) * nbatch * cap);     // + one slot per query for k_merge_keys
     if (rc != ORBX_OK) return rc;
     hipLaunchKernelGGL(k_best2_dense, dim3((cap + M_THREADS - 1) / M_THREADS, nbatch, S), dim3(M_THREADS), 0, s,
                        d_q, d_nq, 0, d_t, d_nt, 0, (long long)cap * 32, (long long)cap * 32, cap, m->d_part);
@@ -542,7 +562,13 @@ extern "C" int orbm_match_batch_device(orbm_matcher *m, const uint8_t *d_q, cons
     int S = 1;
     int rc = launch_dense_batch(m, d_q, d_nq, d_t, d_nt, cap, nbatch, s, &S);
     if (rc != ORBX_OK) return rc;
-    hipLaunchKernelGGL(k_accept_rot, dim3(nbatch), dim3(ACC_THREADS), 0, s, d_nq, d_kq, d_kt, cap, m->d_part, S,
+    const uint2 *part = m->d_part;
+    if (S > ORBM_PREMERGE_SPLITS) {
+        uint2 *merged = m->d_part + (size_t)S * nbatch * cap;
+        hipLaunchKernelGGL(k_merge_keys, dim3((cap + M_THREADS - 1) / M_THREADS, nbatch), dim3(M_THREADS), 0, s, m->d_part, S, d_nq, cap, merged);
+        part = merged; S = 1;
+    }
+    hipLaunchKernelGGL(k_accept_rot, dim3(nbatch), dim3(ACC_THREADS), 0, s, d_nq, d_kq, d_kt, cap, part, S,
                        th, nnratio, check_orientation, d_match12, d_nmatches,
                        (int32_t *)nullptr, (int32_t *)nullptr, (int32_t *)nullptr);
     MHIPCHK(hipGetLastError());

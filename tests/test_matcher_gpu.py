@@ -76,7 +76,10 @@ def test_extract_then_match_frame_pair(orbx, synth):
     assert nm > 300     # the shifted frame really matches
 
 
-@pytest.mark.parametrize("cap,nqs,nts", [(1100, [1000, 0, 1037], [990, 1100, 1]), (5000, [4500, 4999], [4800, 4097])])
+@pytest.mark.parametrize("cap,nqs,nts", [(1100, [1000, 0, 1037], [990, 1100, 1]), (5000, [4500, 4999], [4800, 4097]),
+                                         # 40 pairs: <= 16 train splits, k_accept_rot merges the partials itself; the two
+                                         # cases above have 64 splits and go through the grid-wide k_merge_keys first
+                                         (1100, [1000] * 38 + [0, 1037], [990] * 38 + [1100, 1])])
 def test_match_batch_device(orbx, cap, nqs, nts):
     """Device-resident batched dense match (bench path): acceptance + rotation filter == oracle,
     including the > 4096-query sweep of k_accept_rot and empty / single-descriptor frames."""
