@@ -116,10 +116,11 @@ int orbm_search_area_best2_device(orbm_matcher *m, const uint8_t *d_qdesc, const
  * The two FeatureVectors come from orbv_feature_vector (ascending node ids, CSR feature lists).  For every node both
  * frames share, every key-frame feature with a usable MapPoint (valid_kf[i] != 0: the reference's `pMP && !pMP->isBad()`)
  * scans the frame's features of that node in list order, skipping the ones an earlier key-frame feature already took
- * (`if(vpMapPointMatches[realIdxF]) continue;` :209) -- so the scan order matters and is kept: the Hamming distances of
- * all (key-frame feature, frame feature) pairs of the shared nodes are computed in one GPU call, the sequential
- * best / second-best selection (:214-246), the TH_LOW and ratio tests and the rotation histogram (:236-246, :266-284)
- * run on the host on those distances.  match_f[i] = index of the key-frame feature matched to frame feature i, or -1
+ * (`if(vpMapPointMatches[realIdxF]) continue;` :209) -- so the scan order matters and is kept.  A frame feature lives in
+ * exactly one node, hence nodes are independent: one wave per node walks its key-frame features in order with the node's
+ * frame features across the lanes (best / second-best :214-226, TH_LOW and ratio :228-232); the rotation histogram
+ * (:236-246, :266-284) runs on the host over the match table.  Nodes with more than 4096 frame features take the general
+ * path: all node-mate distances in one GPU call, the same selection scan on the host.  match_f[i] = index of the key-frame feature matched to frame feature i, or -1
  * (the reference's vpMapPointMatches as indices); *nmatches = the function's return value.
  * kps_kf are the key frame's mvKeysUn, kps_f the frame's mvKeys (only .angle is read).
  */

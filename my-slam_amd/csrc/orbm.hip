@@ -605,8 +605,177 @@ extern "C" int orbm_best2_batch_device(orbm_matcher *m, const uint8_t *d_q, cons
     return ORBX_OK;
 }
 
+// ---- N2: SearchByBoW's selection on the GPU (src/ORBmatcher.cc:199-232).  One wave per pair of equal vocabulary nodes: the
+// node's key-frame features are visited in order (the loop is sequential in the reference because a frame feature taken by an
+// earlier key-frame feature is skipped, :209), the lanes hold the node's frame features (position = chunk * 64 + lane, a
+// "taken" bit per chunk in a register), key = distance << 16 | position so that min() is "smallest distance, first in list".
+// A frame feature lives in exactly one node, so nodes do not interact. ----
+#define BOW_NONE ((256u << 16) | 0xFFFFu)
+#define BOW_MAX_NODE_FEATURES 4096      // 64 chunks of 64 lanes
+__global__ __launch_bounds__(M_THREADS) void k_bow_select(
+    const uint8_t *__restrict__ q, const uint8_t *__restrict__ t, const int32_t *__restrict__ kf_idx,
+    const int32_t *__restrict__ f_idx, const int4 *__restrict__ pairs, int npairs, const uint8_t *__restrict__ valid,
+    float nnratio, int32_t *__restrict__ match_f)
+{
+    // the serial loop over a node's key-frame features must not wait for global memory: their descriptors are staged in LDS
+    // 64 at a time (lane j fetches feature j), and the first 64 frame features of the node stay in registers
+    __shared__ uint4 s_q[M_THREADS / 64][64][2];
+    __shared__ int s_ikf[M_THREADS / 64][64];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int w = blockIdx.x * (M_THREADS / 64) + wv;
+    if (w >= npairs) return;                 // whole waves leave; nothing below is a block-wide barrier
+    const int4 p = pairs[w];                 // key-frame range [x, y) of kf_idx, frame range [z, w) of f_idx
+    const int nF = p.w - p.z;
+    const int nch = (nF + 63) >> 6;
+    const bool has0 = lane < nF;
+    const int fi0 = has0 ? f_idx[p.z + lane] : 0;
+    const uint4 *T0 = reinterpret_cast<const uint4 *>(t) + 2 * (long long)fi0;
+    const uint4 t0a = T0[0], t0b = T0[1];
+    unsigned long long taken = 0;
+    for (int c0 = p.x; c0 < p.y; c0 += 64) {
+        const int nb = min(64, p.y - c0);
+        {
+            int ikf = -1;
+            if (lane < nb) {
+                ikf = kf_idx[c0 + lane];
+                if (valid && !valid[ikf]) ikf = -1;      // :193-197
+            }
+            const uint4 *Q = reinterpret_cast<const uint4 *>(q) + 2 * (long long)max(ikf, 0);
+            s_q[wv][lane][0] = Q[0]; s_q[wv][lane][1] = Q[1];
+            s_ikf[wv][lane] = ikf;
+        }
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_s_waitcnt(0xc07f);      // lgkmcnt(0): this wave's LDS writes have landed
+        for (int j = 0; j < nb; j++) {
+            const int ikf = s_ikf[wv][j];
+            if (ikf < 0) continue;               // wave-uniform
+            const uint4 q0 = s_q[wv][j][0], q1 = s_q[wv][j][1];
+            uint32_t bk = BOW_NONE, sk = BOW_NONE;
+            if (has0 && !(taken & 1ull)) bk = ((uint32_t)hamming256(q0, q1, t0a, t0b) << 16) | (uint32_t)lane;
+            for (int ch = 1; ch < nch; ch++) {
+                const int pos = ch * 64 + lane;
+                if (pos < nF && !((taken >> ch) & 1ull)) {
+                    const uint4 *Tj = reinterpret_cast<const uint4 *>(t) + 2 * (long long)f_idx[p.z + pos];
+                    const uint32_t key = ((uint32_t)hamming256(q0, q1, Tj[0], Tj[1]) << 16) | (uint32_t)pos;
+                    sk = med3u(bk, sk, key); bk = min(bk, key);
+                }
+            }
+            uint32_t B = bk;
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) B = min(B, (uint32_t)__shfl_xor((int)B, o));
+            uint32_t S2 = (bk == B) ? sk : bk;   // the winner's position is unique: every other lane offers its best
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) S2 = min(S2, (uint32_t)__shfl_xor((int)S2, o));
+            const int best1 = (int)(B >> 16), best2 = (int)(S2 >> 16);
+            if (best1 <= ORBM_TH_LOW && (float)best1 < __fmul_rn(nnratio, (float)best2)) {     // :228-232
+                const int pos = (int)(B & 0xFFFFu);
+                if (lane == (pos & 63)) {
+                    taken |= 1ull << (pos >> 6);
+                    match_f[f_idx[p.z + pos]] = ikf;
+                }
+            }
+        }
+        __builtin_amdgcn_wave_barrier();         // the next batch overwrites the staging
+    }
+}
+
 // ---- host helpers (ComputeThreeMaxima :1601-1642, histogram fill/cull :236-246,:266-284) ----
-// ---- N2: SearchByBoW (src/ORBmatcher.cc:159-288): distances on the GPU, the order-dependent selection on the host ----
+// rotation histogram + ComputeThreeMaxima cull of SearchByBoW (:236-246, :266-284) on a finished match table
+static int bow_rotation_cull(const orbx_keypoint *kps_kf, const orbx_keypoint *kps_f, int n_f, int check_orientation,
+                             int32_t *match_f, int *nmatches)
+{
+    int32_t hist[ORBM_HISTO_LENGTH] = {0};
+    std::vector<int> bin_of((size_t)n_f, -1);
+    const float factor = 1.0f / ORBM_HISTO_LENGTH;
+    int nm = 0;
+    for (int i = 0; i < n_f; i++) {
+        if (match_f[i] < 0) continue;
+        nm++;
+        if (!check_orientation) continue;
+        float rot = kps_kf[match_f[i]].angle - kps_f[i].angle;
+        if (rot < 0.0) rot += 360.0f;
+        int bin = (int)roundf(rot * factor);
+        if (bin == ORBM_HISTO_LENGTH) bin = 0;
+        if (bin < 0 || bin >= ORBM_HISTO_LENGTH) return mfail(ORBX_E_INVALID, "keypoint angle outside [0, 360)");   // the reference asserts
+        bin_of[i] = bin;
+        hist[bin]++;
+    }
+    if (check_orientation) {
+        int32_t ind[3];
+        orbm_three_maxima(hist, ORBM_HISTO_LENGTH, ind);
+        for (int i = 0; i < n_f; i++)
+            if (bin_of[i] >= 0 && bin_of[i] != ind[0] && bin_of[i] != ind[1] && bin_of[i] != ind[2]) { match_f[i] = -1; nm--; }
+    }
+    *nmatches = nm;
+    return ORBX_OK;
+}
+
+// Returns 1 when the GPU selection does not apply (a node with more than BOW_MAX_NODE_FEATURES frame features, staging larger
+// than the handle's buffers, ORBM_BOW_HOST_SELECT=1 in the environment): the caller then takes the host-selection path.
+static int search_by_bow_device(orbm_matcher *m,
+                                const uint8_t *desc_kf, const orbx_keypoint *kps_kf, int n_kf, const uint8_t *valid_kf,
+                                const int32_t *fv_kf_node, const int32_t *fv_kf_off, const int32_t *fv_kf_idx, int fv_kf_n,
+                                const uint8_t *desc_f, const orbx_keypoint *kps_f, int n_f,
+                                const int32_t *fv_f_node, const int32_t *fv_f_off, const int32_t *fv_f_idx, int fv_f_n,
+                                float nnratio, int check_orientation, int32_t *match_f, int *nmatches)
+{
+    static const bool force_host = [] { const char *e = getenv("ORBM_BOW_HOST_SELECT"); return e && e[0] == '1'; }();
+    if (force_host) return 1;
+    const int nki = fv_kf_off[fv_kf_n], nfi = fv_f_off[fv_f_n];
+    if (nki < 0 || nfi < 0 || n_kf > m->max_q) return 1;
+    std::vector<int4> pairs;
+    for (int a = 0, b = 0; a < fv_kf_n && b < fv_f_n;) {       // merge-join of the ascending node lists (:178-262)
+        if (fv_kf_node[a] == fv_f_node[b]) {
+            if (fv_f_off[b + 1] - fv_f_off[b] > BOW_MAX_NODE_FEATURES) return 1;
+            if (fv_kf_off[a + 1] > fv_kf_off[a] && fv_f_off[b + 1] > fv_f_off[b])
+                pairs.push_back(make_int4(fv_kf_off[a], fv_kf_off[a + 1], fv_f_off[b], fv_f_off[b + 1]));
+            a++; b++;
+        } else if (fv_kf_node[a] < fv_f_node[b]) a++;
+        else b++;
+    }
+    const int np = (int)pairs.size();
+    if (np == 0) return ORBX_OK;
+    for (int c = 0; c < nki; c++)
+        if (fv_kf_idx[c] < 0 || fv_kf_idx[c] >= n_kf) return mfail(ORBX_E_INVALID, "key-frame feature index %d outside [0,%d)", fv_kf_idx[c], n_kf);
+    for (int c = 0; c < nfi; c++)
+        if (fv_f_idx[c] < 0 || fv_f_idx[c] >= n_f) return mfail(ORBX_E_INVALID, "frame feature index %d outside [0,%d)", fv_f_idx[c], n_f);
+    // device ints: [kf_idx | f_idx | pairs (16-byte aligned) | valid bytes] in d_idx, match table in d_out
+    const size_t i_kf = 0, i_f = i_kf + (size_t)nki, i_pairs = (i_f + (size_t)nfi + 3) & ~(size_t)3, i_valid = i_pairs + 4 * (size_t)np;
+    const size_t n_ints = i_valid + (valid_kf ? ((size_t)n_kf + 3) / 4 : 0);
+    const size_t out_ints = std::max<size_t>((size_t)3 * m->max_q, (size_t)m->max_pairs);
+    if (n_ints > (size_t)std::max(m->max_pairs, 1) || (size_t)n_f > out_ints) return 1;
+    MHIPCHK(hipSetDevice(m->device));
+    hipStream_t s = m->stream;
+    const size_t o_q = 0, o_t = o_q + (size_t)n_kf * 32, o_i = o_t + (size_t)n_f * 32, o_m = o_i + n_ints * 4, need = o_m + (size_t)n_f * 4;
+    if (need > m->h_pin_bytes) {
+        MHIPCHK(hipStreamSynchronize(s));
+        (void)hipHostFree(m->h_pin); m->h_pin = nullptr; m->h_pin_bytes = 0;
+        MHIPCHK(hipHostMalloc((void **)&m->h_pin, need + need / 2, hipHostMallocDefault));
+        m->h_pin_bytes = need + need / 2;
+    }
+    memcpy(m->h_pin + o_q, desc_kf, (size_t)n_kf * 32);
+    memcpy(m->h_pin + o_t, desc_f, (size_t)n_f * 32);
+    int32_t *hi = reinterpret_cast<int32_t *>(m->h_pin + o_i);
+    memcpy(hi + i_kf, fv_kf_idx, (size_t)nki * 4);
+    memcpy(hi + i_f, fv_f_idx, (size_t)nfi * 4);
+    memcpy(hi + i_pairs, pairs.data(), (size_t)np * 16);
+    if (valid_kf) memcpy(hi + i_valid, valid_kf, (size_t)n_kf);
+    MHIPCHK(hipMemcpyAsync(m->d_q, m->h_pin + o_q, (size_t)n_kf * 32, hipMemcpyHostToDevice, s));
+    MHIPCHK(hipMemcpyAsync(m->d_t, m->h_pin + o_t, (size_t)n_f * 32, hipMemcpyHostToDevice, s));
+    MHIPCHK(hipMemcpyAsync(m->d_idx, hi, n_ints * 4, hipMemcpyHostToDevice, s));
+    MHIPCHK(hipMemsetAsync(m->d_out, 0xFF, (size_t)n_f * 4, s));        // match table = -1
+    hipLaunchKernelGGL(k_bow_select, dim3((np + M_THREADS / 64 - 1) / (M_THREADS / 64)), dim3(M_THREADS), 0, s,
+                       m->d_q, m->d_t, m->d_idx + i_kf, m->d_idx + i_f, reinterpret_cast<const int4 *>(m->d_idx + i_pairs), np,
+                       valid_kf ? reinterpret_cast<const uint8_t *>(m->d_idx + i_valid) : (const uint8_t *)nullptr, nnratio, m->d_out);
+    MHIPCHK(hipGetLastError());
+    MHIPCHK(hipMemcpyAsync(m->h_pin + o_m, m->d_out, (size_t)n_f * 4, hipMemcpyDeviceToHost, s));
+    MHIPCHK(hipStreamSynchronize(s));
+    memcpy(match_f, m->h_pin + o_m, (size_t)n_f * 4);
+    return bow_rotation_cull(kps_kf, kps_f, n_f, check_orientation, match_f, nmatches);
+}
+
+// ---- N2: SearchByBoW (src/ORBmatcher.cc:159-288).  Usual path: search_by_bow_device above (selection on the GPU).  The rest
+// of this function is the general fallback: every node-mate distance on the GPU, the order-dependent selection on the host ----
 extern "C" int orbm_search_by_bow(orbm_matcher *m,
                                   const uint8_t *desc_kf, const orbx_keypoint *kps_kf, int n_kf, const uint8_t *valid_kf,
                                   const int32_t *fv_kf_node, const int32_t *fv_kf_off, const int32_t *fv_kf_idx, int fv_kf_n,
@@ -622,6 +791,11 @@ extern "C" int orbm_search_by_bow(orbm_matcher *m,
     if (!desc_kf || !kps_kf || !desc_f || !kps_f || !fv_kf_node || !fv_kf_off || !fv_kf_idx || !fv_f_node || !fv_f_off || !fv_f_idx)
         return mfail(ORBX_E_INVALID, "NULL buffer");
     if (n_f > m->max_t) return mfail(ORBX_E_CAPACITY, "n_f=%d exceeds the matcher's max_train=%d", n_f, m->max_t);
+    {   // selection on the GPU when every matched node fits a wave's registers and the staging fits the handle's buffers
+        int rc = search_by_bow_device(m, desc_kf, kps_kf, n_kf, valid_kf, fv_kf_node, fv_kf_off, fv_kf_idx, fv_kf_n, desc_f, kps_f, n_f,
+                                      fv_f_node, fv_f_off, fv_f_idx, fv_f_n, nnratio, check_orientation, match_f, nmatches);
+        if (rc != 1) return rc;    // 1 = not applicable: distances on the GPU, selection on the host (below)
+    }
     // merge-join of the two ascending node lists (:178-262); queries = usable key-frame features in visiting order
     struct Q { int kf, f_node; };
     std::vector<Q> qs;

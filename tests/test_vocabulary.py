@@ -176,3 +176,23 @@ def test_search_by_bow_equals_oracle(orbx, synth, tmp_path, nnratio, check_ori, 
     e = (np.zeros(0, np.int32), np.zeros(1, np.int32), np.zeros(0, np.int32))
     mf2, nm2 = m.SearchByBoW(k0, d0, e, k1, d1, fv1)
     assert nm2 == 0 and (mf2 == -1).all()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("levelsup", [0, 1, 3])
+def test_search_by_bow_node_sizes(orbx, synth, tmp_path, levelsup):
+    """Node granularity from single words (a handful of features per node) to the root (every feature in one node: 16
+    chunks of 64 lanes in k_bow_select, and every key-frame feature competes for every frame feature)."""
+    path = str(tmp_path / "voc.txt")
+    make_vocabulary(path, 10, 3, seed=9)
+    v = orbx.ORBVocabulary(path)
+    f0, f1 = synth.frame_pair(3, 640, 480)
+    ex = orbx.ORBextractor(1000, max_width=640, max_height=480)
+    k0, d0 = ex(f0); k1, d1 = ex(f1)
+    _, fv0 = v.transform(d0, levelsup)
+    _, fv1 = v.transform(d1, levelsup)
+    m = orbx.ORBmatcher(0.75, True, max_queries=4096, max_train=4096, max_pairs=1 << 21)
+    mf, nm = m.SearchByBoW(k0, d0, fv0, k1, d1, fv1)
+    omf, onm = O.search_by_bow(d0, k0["angle"], fv0, d1, k1["angle"], fv1, 0.75, True, None)
+    assert nm == onm and np.array_equal(mf, omf)
+    assert nm > 20
