@@ -793,7 +793,6 @@ struct PoseProblem {
             J[0][3] = -invz * fx; J[0][4] = 0; J[0][5] = x * invz_2 * fx;
             J[1][0] = (1 + y * y * invz_2) * fy; J[1][1] = -x * y * invz_2 * fy; J[1][2] = -x * invz * fy;
             J[1][3] = 0; J[1][4] = -invz * fy; J[1][5] = y * invz_2 * fy;
-            const int D = e.stereo ? 3 : 2;
             if (e.stereo) {
                 J[2][0] = J[0][0] - bf * y * invz_2; J[2][1] = J[0][1] + bf * x * invz_2; J[2][2] = J[0][2];
                 J[2][3] = J[0][3]; J[2][4] = 0; J[2][5] = J[0][5] - bf * invz_2;
@@ -801,15 +800,24 @@ struct PoseProblem {
             double w = 1.0;
             if (e.robust) { double rho[2]; huber(e, chi2(e), rho); w = rho[1]; }
             const double wi = w * e.info;
-            int u = 0;
-            for (int r = 0; r < 6; r++) {
-                double g = 0;
-                for (int d = 0; d < D; d++) g += J[d][r] * e.info * e.err[d];
-                b[r] -= w * g;
-                for (int c = r; c < 6; c++, u++) {
-                    double h = 0;
-                    for (int d = 0; d < D; d++) h += J[d][r] * wi * J[d][c];
-                    Hu[u] += h;
+            // b -= rho' J^T Omega e and H += J^T (rho' Omega) J, upper triangle; written out per row count so the
+            // compiler sees fixed trip counts (the sums keep the order 0 + row0 + row1 (+ row2))
+            double wJ[3][6];
+            for (int r = 0; r < 6; r++) { wJ[0][r] = J[0][r] * wi; wJ[1][r] = J[1][r] * wi; }
+            if (!e.stereo) {
+                int u = 0;
+                for (int r = 0; r < 6; r++) {
+                    const double g = J[0][r] * e.info * e.err[0] + J[1][r] * e.info * e.err[1];
+                    b[r] -= w * g;
+                    for (int c = r; c < 6; c++, u++) Hu[u] += wJ[0][r] * J[0][c] + wJ[1][r] * J[1][c];
+                }
+            } else {
+                for (int r = 0; r < 6; r++) wJ[2][r] = J[2][r] * wi;
+                int u = 0;
+                for (int r = 0; r < 6; r++) {
+                    const double g = J[0][r] * e.info * e.err[0] + J[1][r] * e.info * e.err[1] + J[2][r] * e.info * e.err[2];
+                    b[r] -= w * g;
+                    for (int c = r; c < 6; c++, u++) Hu[u] += wJ[0][r] * J[0][c] + wJ[1][r] * J[1][c] + wJ[2][r] * J[2][c];
                 }
             }
         }
@@ -823,9 +831,13 @@ struct PoseProblem {
     {
         double lambda = 0, ni = 2;
         int n_bad = 0;
+        // g2o recomputes the active errors and their robust chi2 at the top of every iteration; right after an accepted
+        // step they are exactly what the trial left on the edges, so that pass is skipped (same values, same sum)
+        bool fresh = false;
+        double carried = 0;
         for (int it = 0; it < iterations; it++) {
-            compute_active_errors();
-            double current = active_robust_chi2(), temp = current;
+            if (!fresh) { compute_active_errors(); carried = active_robust_chi2(); }
+            double current = carried, temp = current;
             const double ini = current;
             double H[36], b[6], x[6];
             build_system(H, b);
@@ -858,10 +870,12 @@ struct PoseProblem {
                     lambda *= std::max(1. / 3., alpha);
                     ni = 2;
                     current = temp;
+                    fresh = true; carried = temp;
                 } else {
                     lambda *= ni;
                     ni *= 2;
                     est = backup;          // the edges keep the trial's errors, as in g2o
+                    fresh = false;
                 }
                 qmax++;
             } while (rho < 0 && qmax < 10);
