@@ -4,8 +4,8 @@
     extract (GPU) -> Frame grid (GPU) -> ComputeBoW (GPU descent + host maps)
     -> TrackReferenceKeyFrame's ORBmatcher::SearchByBoW (orbm_search_by_bow: TH_LOW, ratio 0.7, rotation filter)
     -> TrackWithMotionModel-style windowed search around the previous positions (GPU, TH_HIGH, rotation filter)
-EPnP RANSAC and g2o pose optimisation (src/PnPsolver.cc, src/Optimizer.cc) are host-side dense fp64 solves and are
-not part of this repository; the harness reports the front-end + matching time per frame.
+EPnP RANSAC and g2o pose optimisation (src/PnPsolver.cc, src/Optimizer.cc) are host-side dense fp64 solves (include/orbp.h); the
+C++ harness tools/track/track_harness.cc runs them in the loop, this script reports the front-end + matching time per frame.
 Everything goes through the host-buffer C ABI, i.e. PCIe transfers and Python dispatch are inside the numbers."""
 import json, os, sys, tempfile, time
 import numpy as np
