@@ -211,6 +211,25 @@ extern "C" int orbv_transform_features(orbv_vocabulary *v, const uint8_t *desc, 
     return ORBX_OK;
 }
 
+// Keys are (id << 32 | feature index) pushed in ascending feature order, so a *stable* sort on the id alone gives the
+// (id, feature index) order of the reference's std::map / push_back.  LSD radix on 11-bit digits of the id: 2000 keys in
+// ~15 us where std::sort takes ~75 us.
+static void sort_by_id_stable(std::vector<unsigned long long> &key)
+{
+    const size_t n = key.size();
+    if (n < 64) { std::sort(key.begin(), key.end()); return; }
+    uint32_t mx = 0;
+    for (unsigned long long k : key) mx = std::max(mx, (uint32_t)(k >> 32));
+    std::vector<unsigned long long> tmp(n);
+    for (int shift = 32; shift < 64 && (mx >> (shift - 32)) != 0; shift += 11) {
+        uint32_t cnt[2049] = {0};
+        for (size_t i = 0; i < n; i++) cnt[((key[i] >> shift) & 2047u) + 1]++;
+        for (int i = 0; i < 2048; i++) cnt[i + 1] += cnt[i];
+        for (size_t i = 0; i < n; i++) tmp[cnt[(key[i] >> shift) & 2047u]++] = key[i];
+        key.swap(tmp);
+    }
+}
+
 // TemplatedVocabulary.h:1143-1193 + BowVector.cpp:34-84
 extern "C" int orbv_bow_vector(const orbv_vocabulary *v, const int32_t *word_id, const double *weight, int n,
                                int32_t *ids, double *vals, int cap)
@@ -225,7 +244,7 @@ extern "C" int orbv_bow_vector(const orbv_vocabulary *v, const int32_t *word_id,
     key.reserve((size_t)n);
     for (int i = 0; i < n; i++)
         if (weight[i] > 0) key.push_back(((unsigned long long)(uint32_t)word_id[i] << 32) | (uint32_t)i);
-    std::sort(key.begin(), key.end());
+    sort_by_id_stable(key);
     std::vector<int32_t> bid; std::vector<double> bval;
     bid.reserve(key.size()); bval.reserve(key.size());
     const bool tf = v->weighting == ORBV_TF || v->weighting == ORBV_TF_IDF;
@@ -263,7 +282,7 @@ extern "C" int orbv_feature_vector(const int32_t *node_id, const double *weight,
     key.reserve((size_t)n);
     for (int i = 0; i < n; i++)
         if (weight[i] > 0) key.push_back(((unsigned long long)(uint32_t)node_id[i] << 32) | (uint32_t)i);
-    std::sort(key.begin(), key.end());
+    sort_by_id_stable(key);
     int o = 0;
     off[0] = 0;
     for (size_t a = 0; a < key.size(); a++) {
