@@ -196,3 +196,18 @@ def test_search_by_bow_node_sizes(orbx, synth, tmp_path, levelsup):
     omf, onm = O.search_by_bow(d0, k0["angle"], fv0, d1, k1["angle"], fv1, 0.75, True, None)
     assert nm == onm and np.array_equal(mf, omf)
     assert nm > 20
+
+
+@pytest.mark.gpu
+def test_search_by_bow_host_selection_fallback():
+    """The general path of orbm_search_by_bow (all node-mate distances on the GPU, selection scan on the host) is what
+    nodes with more than 4096 frame features take; ORBM_BOW_HOST_SELECT=1 forces it.  Same tests, in a child process
+    because the switch is read once per process."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, ORBM_BOW_HOST_SELECT="1")
+    r = subprocess.run([sys.executable, "-m", "pytest", "-x", "-q", "-m", "gpu", "-k", "search_by_bow_equals_oracle or search_by_bow_node_sizes",
+                        os.path.join(root, "tests", "test_vocabulary.py")], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert "6 passed" in r.stdout
