@@ -612,13 +612,28 @@ extern "C" int orbm_best2_batch_device(orbm_matcher *m, const uint8_t *d_q, cons
 // A frame feature lives in exactly one node, so nodes do not interact. ----
 #define BOW_NONE ((256u << 16) | 0xFFFFu)
 #define BOW_MAX_NODE_FEATURES 4096      // 64 chunks of 64 lanes
+#define BOW_REG_CHUNKS 4                // frame features 0..255 of a node stay in registers
+
+// wave-wide minimum, every lane gets it: butterfly inside each row of 16 lanes with DPP (quad swaps, half-row and row mirror),
+// then the four row results through v_readlane.  ~10 instructions; six ds_bpermute steps are several hundred cycles.
+__device__ __forceinline__ uint32_t wave_min_u32(uint32_t v)
+{
+    v = min(v, (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, 0xB1, 0xf, 0xf, false));     // quad_perm [1,0,3,2]
+    v = min(v, (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x4E, 0xf, 0xf, false));     // quad_perm [2,3,0,1]
+    v = min(v, (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x141, 0xf, 0xf, false));    // row_half_mirror
+    v = min(v, (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x140, 0xf, 0xf, false));    // row_mirror
+    const uint32_t r0 = (uint32_t)__builtin_amdgcn_readlane((int)v, 0), r1 = (uint32_t)__builtin_amdgcn_readlane((int)v, 16);
+    const uint32_t r2 = (uint32_t)__builtin_amdgcn_readlane((int)v, 32), r3 = (uint32_t)__builtin_amdgcn_readlane((int)v, 48);
+    return min(min(r0, r1), min(r2, r3));
+}
+
 __global__ __launch_bounds__(M_THREADS) void k_bow_select(
     const uint8_t *__restrict__ q, const uint8_t *__restrict__ t, const int32_t *__restrict__ kf_idx,
     const int32_t *__restrict__ f_idx, const int4 *__restrict__ pairs, int npairs, const uint8_t *__restrict__ valid,
     float nnratio, int32_t *__restrict__ match_f)
 {
     // the serial loop over a node's key-frame features must not wait for global memory: their descriptors are staged in LDS
-    // 64 at a time (lane j fetches feature j), and the first 64 frame features of the node stay in registers
+    // 64 at a time (lane j fetches feature j), and the first 256 frame features of the node stay in registers
     __shared__ uint4 s_q[M_THREADS / 64][64][2];
     __shared__ int s_ikf[M_THREADS / 64][64];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
@@ -627,10 +642,14 @@ __global__ __launch_bounds__(M_THREADS) void k_bow_select(
     const int4 p = pairs[w];                 // key-frame range [x, y) of kf_idx, frame range [z, w) of f_idx
     const int nF = p.w - p.z;
     const int nch = (nF + 63) >> 6;
-    const bool has0 = lane < nF;
-    const int fi0 = has0 ? f_idx[p.z + lane] : 0;
-    const uint4 *T0 = reinterpret_cast<const uint4 *>(t) + 2 * (long long)fi0;
-    const uint4 t0a = T0[0], t0b = T0[1];
+    uint4 ta[BOW_REG_CHUNKS], tb[BOW_REG_CHUNKS];
+#pragma unroll
+    for (int ch = 0; ch < BOW_REG_CHUNKS; ch++) {
+        const int pos = ch * 64 + lane;
+        const int fi = pos < nF ? f_idx[p.z + pos] : 0;
+        const uint4 *T = reinterpret_cast<const uint4 *>(t) + 2 * (long long)fi;
+        ta[ch] = T[0]; tb[ch] = T[1];
+    }
     unsigned long long taken = 0;
     for (int c0 = p.x; c0 < p.y; c0 += 64) {
         const int nb = min(64, p.y - c0);
@@ -651,8 +670,14 @@ __global__ __launch_bounds__(M_THREADS) void k_bow_select(
             if (ikf < 0) continue;               // wave-uniform
             const uint4 q0 = s_q[wv][j][0], q1 = s_q[wv][j][1];
             uint32_t bk = BOW_NONE, sk = BOW_NONE;
-            if (has0 && !(taken & 1ull)) bk = ((uint32_t)hamming256(q0, q1, t0a, t0b) << 16) | (uint32_t)lane;
-            for (int ch = 1; ch < nch; ch++) {
+#pragma unroll
+            for (int ch = 0; ch < BOW_REG_CHUNKS; ch++) {
+                const int pos = ch * 64 + lane;
+                const uint32_t key = ((uint32_t)hamming256(q0, q1, ta[ch], tb[ch]) << 16) | (uint32_t)pos;
+                const uint32_t k2 = (pos < nF && !((taken >> ch) & 1ull)) ? key : BOW_NONE;
+                sk = med3u(bk, sk, k2); bk = min(bk, k2);
+            }
+            for (int ch = BOW_REG_CHUNKS; ch < nch; ch++) {
                 const int pos = ch * 64 + lane;
                 if (pos < nF && !((taken >> ch) & 1ull)) {
                     const uint4 *Tj = reinterpret_cast<const uint4 *>(t) + 2 * (long long)f_idx[p.z + pos];
@@ -660,12 +685,8 @@ __global__ __launch_bounds__(M_THREADS) void k_bow_select(
                     sk = med3u(bk, sk, key); bk = min(bk, key);
                 }
             }
-            uint32_t B = bk;
-#pragma unroll
-            for (int o = 32; o > 0; o >>= 1) B = min(B, (uint32_t)__shfl_xor((int)B, o));
-            uint32_t S2 = (bk == B) ? sk : bk;   // the winner's position is unique: every other lane offers its best
-#pragma unroll
-            for (int o = 32; o > 0; o >>= 1) S2 = min(S2, (uint32_t)__shfl_xor((int)S2, o));
+            const uint32_t B = wave_min_u32(bk);
+            const uint32_t S2 = wave_min_u32((bk == B) ? sk : bk);   // the winner's position is unique: every other lane offers its best
             const int best1 = (int)(B >> 16), best2 = (int)(S2 >> 16);
             if (best1 <= ORBM_TH_LOW && (float)best1 < __fmul_rn(nnratio, (float)best2)) {     // :228-232
                 const int pos = (int)(B & 0xFFFFu);
