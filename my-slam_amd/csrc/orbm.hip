@@ -35,6 +35,8 @@ int orbm_arena_begin(orbm_matcher *m)
         (void)hipHostFree(m->arena); m->arena = nullptr; m->arena_cap = 0;
         const size_t cap = m->arena_want + m->arena_want / 2 + (64u << 10);
         MHIPCHK(hipHostMalloc((void **)&m->arena, cap, hipHostMallocDefault));
+        (void)hipFree(m->d_arena); m->d_arena = nullptr;
+        if (hipMalloc((void **)&m->d_arena, cap) != hipSuccess) { m->d_arena = nullptr; (void)hipGetLastError(); }
         m->arena_cap = cap;
     }
     m->arena_used = 0; m->arena_want = 0; m->npend = 0;
@@ -63,6 +65,47 @@ int orbm_d2h(orbm_matcher *m, void *host, const void *dev, size_t bytes, hipStre
     void *p = m->npend < 8 ? arena_take(m, bytes) : nullptr;
     if (p) { m->pend[m->npend++] = {host, p, bytes}; host = p; }
     MHIPCHK(hipMemcpyAsync(host, dev, bytes, hipMemcpyDeviceToHost, s));
+    return ORBX_OK;
+}
+void *orbm_stage_in(orbm_matcher *m, const void *host, size_t bytes)
+{
+    if (!m->d_arena) { m->arena_want += (bytes + 63) & ~(size_t)63; return nullptr; }
+    void *p = arena_take(m, bytes);
+    if (!p) return nullptr;
+    memcpy(p, host, bytes);
+    return m->d_arena + ((uint8_t *)p - m->arena);
+}
+int orbm_flush_in(orbm_matcher *m, size_t from, hipStream_t s)
+{
+    if (m->arena_used > from)
+        MHIPCHK(hipMemcpyAsync(m->d_arena + from, m->arena + from, m->arena_used - from, hipMemcpyHostToDevice, s));
+    return ORBX_OK;
+}
+void *orbm_d2h_tmp(orbm_matcher *m, const void *dev, size_t bytes, hipStream_t s)
+{
+    void *p = arena_take(m, bytes);
+    if (!p) return nullptr;
+    if (hipMemcpyAsync(p, dev, bytes, hipMemcpyDeviceToHost, s) != hipSuccess) return nullptr;
+    return p;
+}
+int orbm_d2h_split(orbm_matcher *m, void *const *host, const size_t *parts, int nparts, const void *dev, hipStream_t s)
+{
+    size_t total = 0;
+    for (int i = 0; i < nparts; i++) total += parts[i];
+    if (total == 0) return ORBX_OK;
+    uint8_t *p = (m->npend + nparts <= 8) ? (uint8_t *)arena_take(m, total) : nullptr;
+    if (!p) {     // no room in the arena this call: one copy per part
+        size_t o = 0;
+        for (int i = 0; i < nparts; i++) {
+            int rc = orbm_d2h(m, host[i], (const uint8_t *)dev + o, parts[i], s);
+            if (rc != ORBX_OK) return rc;
+            o += parts[i];
+        }
+        return ORBX_OK;
+    }
+    MHIPCHK(hipMemcpyAsync(p, dev, total, hipMemcpyDeviceToHost, s));
+    size_t o = 0;
+    for (int i = 0; i < nparts; i++) { m->pend[m->npend++] = {host[i], p + o, parts[i]}; o += parts[i]; }
     return ORBX_OK;
 }
 int orbm_sync(orbm_matcher *m, hipStream_t s)
@@ -396,7 +439,7 @@ extern "C" void orbm_destroy(orbm_matcher *m)
     (void)hipFree(m->grid.kx); (void)hipFree(m->grid.ky); (void)hipFree(m->grid.koct); (void)hipFree(m->grid.cell_start);
     (void)hipFree(m->grid.items); (void)hipFree(m->grid.cell_of); (void)hipFree(m->d_qf); (void)hipFree(m->d_qi); (void)hipFree(m->d_skip);
     if (m->stream) (void)hipStreamDestroy(m->stream);
-    (void)hipHostFree(m->h_pin); (void)hipHostFree(m->arena);
+    (void)hipHostFree(m->h_pin); (void)hipHostFree(m->arena); (void)hipFree(m->d_arena);
     delete m;
 }
 
@@ -650,6 +693,7 @@ __global__ __launch_bounds__(M_THREADS) void k_bow_select(
         const uint4 *T = reinterpret_cast<const uint4 *>(t) + 2 * (long long)fi;
         ta[ch] = T[0]; tb[ch] = T[1];
     }
+    for (int pos = lane; pos < nF; pos += 64) match_f[f_idx[p.z + pos]] = -1;     // this wave owns these entries
     unsigned long long taken = 0;
     for (int c0 = p.x; c0 < p.y; c0 += 64) {
         const int nb = min(64, p.y - c0);
@@ -767,6 +811,31 @@ static int search_by_bow_device(orbm_matcher *m,
     if (n_ints > (size_t)std::max(m->max_pairs, 1) || (size_t)n_f > out_ints) return 1;
     MHIPCHK(hipSetDevice(m->device));
     hipStream_t s = m->stream;
+    {   // usual path: everything staged in the pinned arena, one copy up, one kernel, one copy back
+        int rc_ = orbm_arena_begin(m);
+        if (rc_ != ORBX_OK) return rc_;
+        const size_t mark = m->arena_used;
+        const uint8_t *dq = (const uint8_t *)orbm_stage_in(m, desc_kf, (size_t)n_kf * 32), *dt = (const uint8_t *)orbm_stage_in(m, desc_f, (size_t)n_f * 32);
+        const int32_t *dki = (const int32_t *)orbm_stage_in(m, fv_kf_idx, (size_t)nki * 4), *dfi = (const int32_t *)orbm_stage_in(m, fv_f_idx, (size_t)nfi * 4);
+        const int4 *dp = (const int4 *)orbm_stage_in(m, pairs.data(), (size_t)np * 16);
+        const uint8_t *dv = valid_kf ? (const uint8_t *)orbm_stage_in(m, valid_kf, (size_t)n_kf) : nullptr;
+        if (dq && dt && dki && dfi && dp && (dv || !valid_kf)) {
+            rc_ = orbm_flush_in(m, mark, s);
+            if (rc_ != ORBX_OK) return rc_;
+            hipLaunchKernelGGL(k_bow_select, dim3((np + M_THREADS / 64 - 1) / (M_THREADS / 64)), dim3(M_THREADS), 0, s,
+                               dq, dt, dki, dfi, dp, np, dv, nnratio, m->d_out);
+            MHIPCHK(hipGetLastError());
+            const int32_t *out = (const int32_t *)orbm_d2h_tmp(m, m->d_out, (size_t)n_f * 4, s);
+            if (out) {
+                rc_ = orbm_sync(m, s);
+                if (rc_ != ORBX_OK) return rc_;
+                for (int k = 0; k < np; k++)         // the kernel wrote the entries of the paired nodes only
+                    for (int c = pairs[k].z; c < pairs[k].w; c++) match_f[fv_f_idx[c]] = out[fv_f_idx[c]];
+                return bow_rotation_cull(kps_kf, kps_f, n_f, check_orientation, match_f, nmatches);
+            }
+            MHIPCHK(hipStreamSynchronize(s));      // no room for the result this call: take the slower path below
+        }
+    }
     const size_t o_q = 0, o_t = o_q + (size_t)n_kf * 32, o_i = o_t + (size_t)n_f * 32, o_m = o_i + n_ints * 4, need = o_m + (size_t)n_f * 4;
     if (need > m->h_pin_bytes) {
         MHIPCHK(hipStreamSynchronize(s));

@@ -341,24 +341,43 @@ extern "C" int orbm_search_area_best2(orbm_matcher *m, const uint8_t *qdesc, con
     MHIPCHK(hipSetDevice(m->device));
     { int rc_ = orbm_arena_begin(m); if (rc_ != ORBX_OK) return rc_; }
     hipStream_t s = m->stream;
-    int rc = upload_windows(m, x, y, r, min_level, max_level, nq, s);
-    if (rc != ORBX_OK) return rc;
-    const size_t Q = m->qf_elems;
-    { int rc_ = orbm_h2d(m, m->d_q, qdesc, (size_t)nq * 32, s); if (rc_ != ORBX_OK) return rc_; }
-    if (m->grid.n > 0) { int rc_ = orbm_h2d(m, m->d_t, train_desc, (size_t)m->grid.n * 32, s); if (rc_ != ORBX_OK) return rc_; }
-    const uint8_t *d_skip = nullptr;
-    if (skip && m->grid.n > 0) {
-        if (!m->d_skip) MHIPCHK(hipMalloc((void **)&m->d_skip, (size_t)m->max_t));
-        { int rc_ = orbm_h2d(m, m->d_skip, skip, (size_t)m->grid.n, s); if (rc_ != ORBX_OK) return rc_; }
-        d_skip = m->d_skip;
-    }
+    int rc;
     int32_t *o_bi = m->d_out, *o_bd = m->d_out + nq, *o_sd = m->d_out + 2 * (size_t)nq;
-    rc = orbm_search_area_best2_device(m, m->d_q, m->d_qf, m->d_qf + Q, m->d_qf + 2 * Q, m->d_qi, m->d_qi + Q, nq, m->d_t, d_skip,
-                                       o_bi, o_bd, o_sd, s);
-    if (rc != ORBX_OK) return rc;
-    { int rc_ = orbm_d2h(m, best_idx, o_bi, (size_t)nq * 4, s); if (rc_ != ORBX_OK) return rc_; }
-    { int rc_ = orbm_d2h(m, best_d, o_bd, (size_t)nq * 4, s); if (rc_ != ORBX_OK) return rc_; }
-    { int rc_ = orbm_d2h(m, second_d, o_sd, (size_t)nq * 4, s); if (rc_ != ORBX_OK) return rc_; }
+    // usual path: every input of the call is staged in the pinned arena and goes up in one copy to its device mirror
+    const size_t mark = m->arena_used;
+    const size_t nb4 = (size_t)nq * 4;
+    const float *sx = (const float *)orbm_stage_in(m, x, nb4), *sy = (const float *)orbm_stage_in(m, y, nb4), *sr = (const float *)orbm_stage_in(m, r, nb4);
+    const int32_t *smn = (const int32_t *)orbm_stage_in(m, min_level, nb4), *smx = (const int32_t *)orbm_stage_in(m, max_level, nb4);
+    const uint8_t *sq = (const uint8_t *)orbm_stage_in(m, qdesc, (size_t)nq * 32);
+    const uint8_t *st = m->grid.n > 0 ? (const uint8_t *)orbm_stage_in(m, train_desc, (size_t)m->grid.n * 32) : m->d_t;
+    const uint8_t *ss = (skip && m->grid.n > 0) ? (const uint8_t *)orbm_stage_in(m, skip, (size_t)m->grid.n) : nullptr;
+    if (sx && sy && sr && smn && smx && sq && st && (ss || !(skip && m->grid.n > 0))) {
+        rc = orbm_flush_in(m, mark, s);
+        if (rc != ORBX_OK) return rc;
+        rc = orbm_search_area_best2_device(m, sq, sx, sy, sr, smn, smx, nq, st, ss, o_bi, o_bd, o_sd, s);
+        if (rc != ORBX_OK) return rc;
+    } else {     // first call / arena too small: per-array copies into the fixed buffers (the arena grows for the next call)
+        rc = upload_windows(m, x, y, r, min_level, max_level, nq, s);
+        if (rc != ORBX_OK) return rc;
+        const size_t Q = m->qf_elems;
+        { int rc_ = orbm_h2d(m, m->d_q, qdesc, (size_t)nq * 32, s); if (rc_ != ORBX_OK) return rc_; }
+        if (m->grid.n > 0) { int rc_ = orbm_h2d(m, m->d_t, train_desc, (size_t)m->grid.n * 32, s); if (rc_ != ORBX_OK) return rc_; }
+        const uint8_t *d_skip = nullptr;
+        if (skip && m->grid.n > 0) {
+            if (!m->d_skip) MHIPCHK(hipMalloc((void **)&m->d_skip, (size_t)m->max_t));
+            { int rc_ = orbm_h2d(m, m->d_skip, skip, (size_t)m->grid.n, s); if (rc_ != ORBX_OK) return rc_; }
+            d_skip = m->d_skip;
+        }
+        rc = orbm_search_area_best2_device(m, m->d_q, m->d_qf, m->d_qf + Q, m->d_qf + 2 * Q, m->d_qi, m->d_qi + Q, nq, m->d_t, d_skip,
+                                           o_bi, o_bd, o_sd, s);
+        if (rc != ORBX_OK) return rc;
+    }
+    {
+        void *const hosts[3] = {best_idx, best_d, second_d};
+        const size_t parts[3] = {nb4, nb4, nb4};
+        int rc_ = orbm_d2h_split(m, hosts, parts, 3, o_bi, s);
+        if (rc_ != ORBX_OK) return rc_;
+    }
     { int rc_ = orbm_sync(m, s); if (rc_ != ORBX_OK) return rc_; }
     return ORBX_OK;
 }

@@ -54,11 +54,20 @@ struct orbm_matcher {
     // pinned bump arena for the host-buffer entry points: pageable hipMemcpyAsync is a staged, synchronous copy of tens of
     // microseconds each; through pinned memory the copies of one call queue up behind each other and cost one round trip
     uint8_t *arena = nullptr; size_t arena_cap = 0, arena_used = 0, arena_want = 0;
+    uint8_t *d_arena = nullptr;     // device mirror of the arena: inputs staged with orbm_stage_in() go up in ONE copy
     struct Pend { void *dst; const void *src; size_t bytes; };
     Pend pend[8]; int npend = 0;
 };
 int orbm_arena_begin(orbm_matcher *m);                                                    // start of a host-API call
 int orbm_h2d(orbm_matcher *m, void *dev, const void *host, size_t bytes, hipStream_t s);   // staged host -> device copy
 int orbm_d2h(orbm_matcher *m, void *host, const void *dev, size_t bytes, hipStream_t s);   // staged; lands in host at orbm_sync()
-int orbm_sync(orbm_matcher *m, hipStream_t s);                                            // synchronise + deliver the D2H copies
+int orbm_sync(orbm_matcher *m, hipStream_t s);
+// Staged input: copies into the pinned arena and returns where it will be in the device mirror after orbm_flush_in()
+// (every hipMemcpyAsync costs ~7 us of host time, so the inputs of one call travel together).  NULL: no room this call.
+void *orbm_stage_in(orbm_matcher *m, const void *host, size_t bytes);
+int orbm_flush_in(orbm_matcher *m, size_t from, hipStream_t s);                            // uploads arena[from, used)
+// device -> pinned arena; returns where the bytes are after orbm_sync() (NULL: no room this call)
+void *orbm_d2h_tmp(orbm_matcher *m, const void *dev, size_t bytes, hipStream_t s);
+// one device block -> up to four host arrays, one copy (parts[i] bytes each, consecutive in the block)
+int orbm_d2h_split(orbm_matcher *m, void *const *host, const size_t *parts, int nparts, const void *dev, hipStream_t s);                                            // synchronise + deliver the D2H copies
 
