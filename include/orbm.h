@@ -97,6 +97,19 @@ int orbm_match_batch_device(orbm_matcher *m, const uint8_t *d_q, const orbx_keyp
  *                   the strict-'<' tie rules; skip[i] != 0 drops train keypoint i (the reference's
  *                   `continue` predicates).  *_device takes device pointers and does not synchronise.
  */
+/*
+ * Frame::UndistortKeyPoints (src/Frame.cc:404-434) and Frame::ComputeImageBounds (:436-463): host code, they run once per
+ * frame on ~10^3 points between orbx_extract and orbm_grid_build.  dist = mDistCoef (k1, k2, p1, p2[, k3]); ndist = 4 or 5.
+ * With dist[0] == 0 both are the identity exactly as in the reference (:406-410, :455-461).  Otherwise the points go
+ * through cv::undistortPoints(src, dst, K, dist, noArray(), K) of OpenCV 3.1.0, restated: normalise with K, five fixed-point
+ * iterations x <- (x0 - deltaX(x)) * icdist(x) of the Brown model in double, reproject with K, store as float.
+ * kps_un may alias kps.  bounds = {mnMinX, mnMaxX, mnMinY, mnMaxY}.
+ */
+int orbm_undistort_keypoints(const orbx_keypoint *kps, int n, float fx, float fy, float cx, float cy,
+                             const float *dist, int ndist, orbx_keypoint *kps_un);
+int orbm_image_bounds(int width, int height, float fx, float fy, float cx, float cy, const float *dist, int ndist,
+                      float bounds[4]);
+
 int orbm_grid_build(orbm_matcher *m, const orbx_keypoint *kps_un, int n,
                     float min_x, float max_x, float min_y, float max_y);
 int orbm_features_in_area(orbm_matcher *m, const float *x, const float *y, const float *r,

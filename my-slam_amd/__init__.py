@@ -159,6 +159,10 @@ def _bind_matcher(L):
     L.orbm_search_by_bow.argtypes = [vp, vp, vp, C.c_int, vp, vp, vp, vp, C.c_int,
                                      vp, vp, C.c_int, vp, vp, vp, C.c_int, C.c_float, C.c_int, vp, vp]
     L.orbm_three_maxima.argtypes = [vp, C.c_int, vp]
+    L.orbm_undistort_keypoints.argtypes = [vp, C.c_int, C.c_float, C.c_float, C.c_float, C.c_float, vp, C.c_int, vp]
+    L.orbm_undistort_keypoints.restype = C.c_int
+    L.orbm_image_bounds.argtypes = [C.c_int, C.c_int, C.c_float, C.c_float, C.c_float, C.c_float, vp, C.c_int, vp]
+    L.orbm_image_bounds.restype = C.c_int
     L.orbm_last_error.restype = C.c_char_p
     for name in ("orbm_create", "orbm_distance", "orbm_best2", "orbm_distances", "orbm_best2_batch_device",
                  "orbm_match_batch_device", "orbm_rot_filter", "orbm_three_maxima", "orbm_grid_build",
@@ -490,6 +494,23 @@ class ORBVocabulary:
 
     def score(self, bow1, bow2):
         return self.L.orbv_score_l1(_p(bow1[0]), _p(bow1[1]), len(bow1[0]), _p(bow2[0]), _p(bow2[1]), len(bow2[0]))
+
+
+def UndistortKeyPoints(kps, fx, fy, cx, cy, dist_coef):
+    """Frame::UndistortKeyPoints (src/Frame.cc:404-434): mvKeys -> mvKeysUn for mDistCoef = (k1, k2, p1, p2[, k3])."""
+    kps = np.ascontiguousarray(kps, KP_DTYPE)
+    d = np.ascontiguousarray(dist_coef, np.float32)
+    out = np.empty_like(kps)
+    _mchk(lib().orbm_undistort_keypoints(_p(kps), len(kps), fx, fy, cx, cy, _p(d), len(d), _p(out)))
+    return out
+
+
+def ComputeImageBounds(width, height, fx, fy, cx, cy, dist_coef):
+    """Frame::ComputeImageBounds (src/Frame.cc:436-463) -> (mnMinX, mnMaxX, mnMinY, mnMaxY)."""
+    d = np.ascontiguousarray(dist_coef, np.float32)
+    b = np.zeros(4, np.float32)
+    _mchk(lib().orbm_image_bounds(width, height, fx, fy, cx, cy, _p(d), len(d), _p(b)))
+    return tuple(float(v) for v in b)
 
 
 def _pchk(rc):

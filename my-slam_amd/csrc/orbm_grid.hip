@@ -227,6 +227,60 @@ static int ensure_query_staging(orbm_matcher *m, size_t nq)
     return ORBX_OK;
 }
 
+// cv::undistortPoints(src, dst, K, distCoeffs, noArray(), K) of OpenCV 3.1.0 for one point (cvUndistortPoints: camera matrix
+// and coefficients converted to double, ITERS = 5, no tilt, R = I, P = K).  Called by Frame::UndistortKeyPoints (src/Frame.cc:421)
+// and Frame::ComputeImageBounds (:449).
+static inline void undistort_point(float xin, float yin, double fx, double fy, double cx, double cy, const double k[5],
+                                   float *xout, float *yout)
+{
+    const double ifx = 1. / fx, ify = 1. / fy;
+    double x = xin, y = yin;
+    const double x0 = x = (x - cx) * ifx;
+    const double y0 = y = (y - cy) * ify;
+    for (int j = 0; j < 5; j++) {
+        const double r2 = x * x + y * y;
+        const double icdist = (1 + ((0 * r2 + 0) * r2 + 0) * r2) / (1 + ((k[4] * r2 + k[1]) * r2 + k[0]) * r2);     // k4..k6 = 0
+        const double deltaX = 2 * k[2] * x * y + k[3] * (r2 + 2 * x * x);
+        const double deltaY = k[2] * (r2 + 2 * y * y) + 2 * k[3] * x * y;
+        x = (x0 - deltaX) * icdist;
+        y = (y0 - deltaY) * icdist;
+    }
+    const double xx = fx * x + 0 * y + cx, yy = 0 * x + fy * y + cy, ww = 1. / (0 * x + 0 * y + 1);
+    *xout = (float)(xx * ww);
+    *yout = (float)(yy * ww);
+}
+
+extern "C" int orbm_undistort_keypoints(const orbx_keypoint *kps, int n, float fx, float fy, float cx, float cy,
+                                        const float *dist, int ndist, orbx_keypoint *kps_un)
+{
+    if (n < 0 || (n > 0 && (!kps || !kps_un)) || !dist || (ndist != 4 && ndist != 5)) return mfail(ORBX_E_INVALID, "bad argument");
+    if (dist[0] == 0.0f) {                     // :406-410
+        if (kps_un != kps) memmove(kps_un, kps, sizeof(orbx_keypoint) * (size_t)n);
+        return ORBX_OK;
+    }
+    const double k[5] = {dist[0], dist[1], dist[2], dist[3], ndist == 5 ? dist[4] : 0.0};
+    for (int i = 0; i < n; i++) {
+        orbx_keypoint kp = kps[i];
+        undistort_point(kps[i].x, kps[i].y, fx, fy, cx, cy, k, &kp.x, &kp.y);
+        kps_un[i] = kp;
+    }
+    return ORBX_OK;
+}
+
+extern "C" int orbm_image_bounds(int width, int height, float fx, float fy, float cx, float cy, const float *dist, int ndist,
+                                 float bounds[4])
+{
+    if (!dist || !bounds || (ndist != 4 && ndist != 5)) return mfail(ORBX_E_INVALID, "bad argument");
+    if (dist[0] == 0.0f) { bounds[0] = 0.0f; bounds[1] = (float)width; bounds[2] = 0.0f; bounds[3] = (float)height; return ORBX_OK; }
+    const double k[5] = {dist[0], dist[1], dist[2], dist[3], ndist == 5 ? dist[4] : 0.0};
+    const float cxs[4] = {0.f, (float)width, 0.f, (float)width}, cys[4] = {0.f, 0.f, (float)height, (float)height};
+    float ux[4], uy[4];
+    for (int i = 0; i < 4; i++) undistort_point(cxs[i], cys[i], fx, fy, cx, cy, k, &ux[i], &uy[i]);
+    bounds[0] = std::min(ux[0], ux[2]); bounds[1] = std::max(ux[1], ux[3]);      // :451-454
+    bounds[2] = std::min(uy[0], uy[1]); bounds[3] = std::max(uy[2], uy[3]);
+    return ORBX_OK;
+}
+
 extern "C" int orbm_grid_build(orbm_matcher *m, const orbx_keypoint *kps_un, int n,
                                float min_x, float max_x, float min_y, float max_y)
 {

@@ -1336,3 +1336,40 @@ int oro_search_by_bow(const uint8_t *desc_kf, const float *angle_kf, int n_kf, c
     free(rot_items);
     return nmatches;
 }
+
+/* ---- Frame::UndistortKeyPoints / ComputeImageBounds, src/Frame.cc:404-463 ----
+ * cv::undistortPoints of OpenCV 3.1.0 (imgproc/src/undistort.cpp, cvUndistortPoints): camera matrix and distortion
+ * coefficients widened to double, x0 = (u - cx) / fx, then five times x <- (x0 - deltaX) * icdist with
+ * icdist = 1 / (1 + k1 r2 + k2 r2^2 + k3 r2^3) and the tangential deltas, finally u' = fx x + cx stored as float. */
+void oro_undistort_points(float *xy, int n, float fx, float fy, float cx, float cy, const float dist[5])
+{
+    if (dist[0] == 0.0f) return;                       /* :406-410 */
+    const double Fx = fx, Fy = fy, Cx = cx, Cy = cy;
+    const double k1 = dist[0], k2 = dist[1], p1 = dist[2], p2 = dist[3], k3 = dist[4];
+    for (int i = 0; i < n; i++) {
+        const double xn = ((double)xy[2 * i] - Cx) * (1.0 / Fx), yn = ((double)xy[2 * i + 1] - Cy) * (1.0 / Fy);
+        double x = xn, y = yn;
+        for (int it = 0; it < 5; it++) {
+            const double r2 = x * x + y * y;
+            const double icdist = 1.0 / (1 + ((k3 * r2 + k2) * r2 + k1) * r2);
+            const double dx = 2 * p1 * x * y + p2 * (r2 + 2 * x * x);
+            const double dy = p1 * (r2 + 2 * y * y) + 2 * p2 * x * y;
+            x = (xn - dx) * icdist;
+            y = (yn - dy) * icdist;
+        }
+        xy[2 * i] = (float)(Fx * x + Cx);
+        xy[2 * i + 1] = (float)(Fy * y + Cy);
+    }
+}
+
+void oro_image_bounds(int width, int height, float fx, float fy, float cx, float cy, const float dist[5], float bounds[4])
+{
+    float c[8] = {0.f, 0.f, (float)width, 0.f, 0.f, (float)height, (float)width, (float)height};
+    if (dist[0] != 0.0f) {
+        oro_undistort_points(c, 4, fx, fy, cx, cy, dist);
+        bounds[0] = c[0] < c[4] ? c[0] : c[4]; bounds[1] = c[2] > c[6] ? c[2] : c[6];
+        bounds[2] = c[1] < c[3] ? c[1] : c[3]; bounds[3] = c[5] > c[7] ? c[5] : c[7];
+    } else {
+        bounds[0] = 0.0f; bounds[1] = (float)width; bounds[2] = 0.0f; bounds[3] = (float)height;
+    }
+}

@@ -141,6 +141,10 @@ typedef struct {
     int cell_start[ORO_GRID_COLS * ORO_GRID_ROWS + 1];   /* CSR over cells, cell = ix*48 + iy */
     int *items;                             /* keypoint indices, push_back order inside a cell */
 } oro_grid;
+/* Frame::UndistortKeyPoints / ComputeImageBounds (src/Frame.cc:404-463) on cv::undistortPoints(src, dst, K, D, noArray(), K)
+ * of OpenCV 3.1.0 (5 fixed-point iterations in double).  xy: n (x, y) float pairs in place; dist = k1 k2 p1 p2 k3. */
+void oro_undistort_points(float *xy, int n, float fx, float fy, float cx, float cy, const float dist[5]);
+void oro_image_bounds(int width, int height, float fx, float fy, float cx, float cy, const float dist[5], float bounds[4]);
 /* AssignFeaturesToGrid + PosInGrid; items must hold n ints */
 void oro_grid_build(oro_grid *g, const oro_keypoint *kps_un, int n, float min_x, float max_x, float min_y, float max_y, int *items);
 /* GetFeaturesInArea: returns the count written to out (reference order), -1 if cap is too small */

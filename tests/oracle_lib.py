@@ -78,6 +78,10 @@ def lib(native=False):
     L.oro_rot_bin.restype = C.c_int
     L.oro_rot_filter.argtypes = [vp, vp, vp, C.c_int]
     L.oro_rot_filter.restype = C.c_int
+    L.oro_undistort_points.argtypes = [vp, C.c_int, C.c_float, C.c_float, C.c_float, C.c_float, vp]
+    L.oro_undistort_points.restype = None
+    L.oro_image_bounds.argtypes = [C.c_int, C.c_int, C.c_float, C.c_float, C.c_float, C.c_float, vp, vp]
+    L.oro_image_bounds.restype = None
     L.oro_grid_build.argtypes = [vp, vp, C.c_int, C.c_float, C.c_float, C.c_float, C.c_float, vp]
     L.oro_grid_build.restype = None
     L.oro_features_in_area.argtypes = [vp, vp, C.c_float, C.c_float, C.c_float, C.c_int, C.c_int, vp, C.c_int]
@@ -260,3 +264,18 @@ def stereo_matches(ex, kl, dl, kr, dr, pyrL, pyrR, mb, mbf):
     u = np.zeros(len(kl), np.float32); d = np.zeros(len(kl), np.float32)
     ex.L.oro_stereo_matches(C.byref(ex.e), _p(kl), _p(dl), len(kl), _p(kr), _p(dr), len(kr), PL, PR, lw, lh, mb, mbf, _p(u), _p(d))
     return u, d
+
+
+def undistort_points(xy, fx, fy, cx, cy, dist5):
+    """oro_undistort_points on an (n, 2) float32 array -> new array"""
+    xy = np.ascontiguousarray(xy, np.float32).copy()
+    d = np.ascontiguousarray(dist5, np.float32)
+    lib().oro_undistort_points(xy.ctypes.data, len(xy), fx, fy, cx, cy, d.ctypes.data)
+    return xy
+
+
+def image_bounds(w, h, fx, fy, cx, cy, dist5):
+    d = np.ascontiguousarray(dist5, np.float32)
+    b = np.zeros(4, np.float32)
+    lib().oro_image_bounds(w, h, fx, fy, cx, cy, d.ctypes.data, b.ctypes.data)
+    return tuple(float(v) for v in b)
