@@ -98,6 +98,21 @@ int orbm_match_batch_device(orbm_matcher *m, const uint8_t *d_q, const orbx_keyp
  *                   `continue` predicates).  *_device takes device pointers and does not synchronise.
  */
 /*
+ * ORBmatcher::SearchForInitialization (src/ORBmatcher.cc:405-520), the monocular initialiser's matcher.  Frame 2's grid
+ * must be in the handle (orbm_grid_build on F2.mvKeysUn).  For every level-0 keypoint of frame 1 the window
+ * GetFeaturesInArea(vbPrevMatched[i1], windowSize, 0, 0) and the candidates' distances come from the GPU (one
+ * orbm_features_in_area + one orbm_distances pass over all windows); the scan itself is sequential in the reference
+ * (vMatchedDistance / vnMatches21 let a later keypoint steal an earlier one's match, :444, :463-467) and runs on the host
+ * on those distances, as do the rotation histogram -- whose bins keep the entries of stolen matches, as the reference's
+ * rotHist does -- and the cull (:489-510).  prev_matched (2 * n1 floats) is vbPrevMatched, updated in place (:513-516);
+ * matches12[n1] = vnMatches12; *nmatches = the return value.
+ */
+int orbm_search_for_initialization(orbm_matcher *m, const orbx_keypoint *kps1, const uint8_t *desc1, int n1,
+                                   const orbx_keypoint *kps2, const uint8_t *desc2, int n2,
+                                   float *prev_matched, int window_size, float nnratio, int check_orientation,
+                                   int32_t *matches12, int *nmatches);
+
+/*
  * Frame::UndistortKeyPoints (src/Frame.cc:404-434) and Frame::ComputeImageBounds (:436-463): host code, they run once per
  * frame on ~10^3 points between orbx_extract and orbm_grid_build.  dist = mDistCoef (k1, k2, p1, p2[, k3]); ndist = 4 or 5.
  * With dist[0] == 0 both are the identity exactly as in the reference (:406-410, :455-461).  Otherwise the points go

@@ -159,6 +159,8 @@ def _bind_matcher(L):
     L.orbm_search_by_bow.argtypes = [vp, vp, vp, C.c_int, vp, vp, vp, vp, C.c_int,
                                      vp, vp, C.c_int, vp, vp, vp, C.c_int, C.c_float, C.c_int, vp, vp]
     L.orbm_three_maxima.argtypes = [vp, C.c_int, vp]
+    L.orbm_search_for_initialization.argtypes = [vp, vp, vp, C.c_int, vp, vp, C.c_int, vp, C.c_int, C.c_float, C.c_int, vp, vp]
+    L.orbm_search_for_initialization.restype = C.c_int
     L.orbm_undistort_keypoints.argtypes = [vp, C.c_int, C.c_float, C.c_float, C.c_float, C.c_float, vp, C.c_int, vp]
     L.orbm_undistort_keypoints.restype = C.c_int
     L.orbm_image_bounds.argtypes = [C.c_int, C.c_int, C.c_float, C.c_float, C.c_float, C.c_float, vp, C.c_int, vp]
@@ -431,6 +433,19 @@ class ORBmatcher:
         _mchk(self.L.orbm_search_area_best2(self.h, _p(qdesc), _p(x), _p(y), _p(r), _p(mn), _p(mx), nq, _p(train_desc), _p(skip),
                                             _p(bi), _p(bd), _p(sd)))
         return bi, bd, sd
+
+    def SearchForInitialization(self, kps1, desc1, kps2, desc2, prev_matched, windowSize=10):
+        """ORBmatcher::SearchForInitialization(F1, F2, vbPrevMatched, vnMatches12, windowSize) (src/ORBmatcher.cc:405-520).
+        The grid of frame 2 must be current (grid_build(kps2, ...)).  prev_matched (n1, 2) float32 is updated in place;
+        returns (vnMatches12, nmatches)."""
+        kps1 = np.ascontiguousarray(kps1); kps2 = np.ascontiguousarray(kps2)
+        desc1 = np.ascontiguousarray(desc1, np.uint8).reshape(-1, 32); desc2 = np.ascontiguousarray(desc2, np.uint8).reshape(-1, 32)
+        assert prev_matched.dtype == np.float32 and prev_matched.flags["C_CONTIGUOUS"] and prev_matched.shape == (len(kps1), 2)
+        m12 = np.full(len(kps1), -1, np.int32)
+        nm = C.c_int(0)
+        _mchk(self.L.orbm_search_for_initialization(self.h, _p(kps1), _p(desc1), len(kps1), _p(kps2), _p(desc2), len(kps2), _p(prev_matched),
+                                                    int(windowSize), C.c_float(self.mfNNratio), 1 if self.mbCheckOrientation else 0, _p(m12), C.byref(nm)))
+        return m12, nm.value
 
     def SearchByBoW(self, kps_kf, desc_kf, featvec_kf, kps_f, desc_f, featvec_f, valid_kf=None):
         """ORBmatcher::SearchByBoW(KeyFrame*, Frame&, vpMapPointMatches) (src/ORBmatcher.cc:159-288).  featvec_* are the

@@ -7,6 +7,8 @@
 #include <algorithm>
 #include <vector>
 
+#include <climits>
+#include <utility>
 #include "orbm_internal.h"
 #include "orbx_internal.h"
 
@@ -433,5 +435,87 @@ extern "C" int orbm_search_area_best2(orbm_matcher *m, const uint8_t *qdesc, con
         if (rc_ != ORBX_OK) return rc_;
     }
     { int rc_ = orbm_sync(m, s); if (rc_ != ORBX_OK) return rc_; }
+    return ORBX_OK;
+}
+
+// ---- ORBmatcher::SearchForInitialization (src/ORBmatcher.cc:405-520) ----
+extern "C" int orbm_search_for_initialization(orbm_matcher *m, const orbx_keypoint *kps1, const uint8_t *desc1, int n1,
+                                              const orbx_keypoint *kps2, const uint8_t *desc2, int n2,
+                                              float *prev_matched, int window_size, float nnratio, int check_orientation,
+                                              int32_t *matches12, int *nmatches)
+{
+    if (!m) return mfail(ORBX_E_INVALID, "NULL handle");
+    if (n1 < 0 || n2 < 0 || !matches12 || !nmatches || (n1 > 0 && (!kps1 || !desc1 || !prev_matched)) || (n2 > 0 && (!kps2 || !desc2)))
+        return mfail(ORBX_E_INVALID, "bad argument");
+    *nmatches = 0;
+    for (int i = 0; i < n1; i++) matches12[i] = -1;                       // :408
+    if (n1 == 0 || n2 == 0) return ORBX_OK;
+    if (!m->grid_ok || m->grid.n != n2) return mfail(ORBX_E_INVALID, "orbm_grid_build(frame 2) has not been called (grid holds %d keypoints, n2 = %d)", m->grid_ok ? m->grid.n : -1, n2);
+    // the queries: keypoints of frame 1 on level 0 (:421-423), their windows and descriptors
+    std::vector<int> qi;
+    for (int i = 0; i < n1; i++)
+        if (kps1[i].octave <= 0) qi.push_back(i);
+    const int nq = (int)qi.size();
+    if (nq == 0) return ORBX_OK;
+    if (nq > m->max_q) return mfail(ORBX_E_CAPACITY, "%d level-0 keypoints, matcher sized for %d queries", nq, m->max_q);
+    std::vector<float> x(nq), y(nq), r(nq, (float)window_size);
+    std::vector<int32_t> lv(nq), off((size_t)nq + 1), idx((size_t)std::max<long long>(std::min<long long>(m->max_pairs, (long long)nq * n2), 1));
+    std::vector<uint8_t> qd((size_t)nq * 32);
+    for (int k = 0; k < nq; k++) {
+        const int i = qi[k];
+        x[k] = prev_matched[2 * i]; y[k] = prev_matched[2 * i + 1]; lv[k] = kps1[i].octave;
+        memcpy(&qd[(size_t)k * 32], desc1 + (size_t)i * 32, 32);
+    }
+    const int total = orbm_features_in_area(m, x.data(), y.data(), r.data(), lv.data(), lv.data(), nq, off.data(), idx.data(), (int)idx.size());
+    if (total < 0) return total;
+    std::vector<int32_t> dist((size_t)std::max(total, 1));
+    if (total > 0) {
+        int rc = orbm_distances(m, qd.data(), nq, desc2, n2, off.data(), idx.data(), dist.data());
+        if (rc != ORBX_OK) return rc;
+    }
+    // the sequential scan (:418-487)
+    std::vector<int> matched_dist((size_t)n2, INT_MAX), matches21((size_t)n2, -1);
+    std::vector<std::pair<int, int>> rot;           // rotHist as (bin, i1) in push order
+    int32_t hist[ORBM_HISTO_LENGTH] = {0};
+    const float factor = 1.0f / ORBM_HISTO_LENGTH;
+    int nm = 0;
+    for (int k = 0; k < nq; k++) {
+        const int i1 = qi[k];
+        if (off[k + 1] == off[k]) continue;          // :427
+        int bestDist = INT_MAX, bestDist2 = INT_MAX, bestIdx2 = -1;
+        for (int c = off[k]; c < off[k + 1]; c++) {
+            const int i2 = idx[c], d = dist[c];
+            if (matched_dist[i2] <= d) continue;     // :444
+            if (d < bestDist) { bestDist2 = bestDist; bestDist = d; bestIdx2 = i2; }
+            else if (d < bestDist2) bestDist2 = d;
+        }
+        if (bestDist <= ORBM_TH_LOW && (float)bestDist < (float)bestDist2 * nnratio) {     // :459-461
+            if (matches21[bestIdx2] >= 0) { matches12[matches21[bestIdx2]] = -1; nm--; }
+            matches12[i1] = bestIdx2;
+            matches21[bestIdx2] = i1;
+            matched_dist[bestIdx2] = bestDist;
+            nm++;
+            if (check_orientation) {
+                float rot_ = kps1[i1].angle - kps2[bestIdx2].angle;
+                if (rot_ < 0.0) rot_ += 360.0f;
+                int bin = (int)roundf(rot_ * factor);
+                if (bin == ORBM_HISTO_LENGTH) bin = 0;
+                if (bin < 0 || bin >= ORBM_HISTO_LENGTH) return mfail(ORBX_E_INVALID, "keypoint angle outside [0, 360)");   // the reference asserts
+                rot.emplace_back(bin, i1);
+                hist[bin]++;
+            }
+        }
+    }
+    if (check_orientation) {                         // :489-510
+        int32_t ind[3];
+        orbm_three_maxima(hist, ORBM_HISTO_LENGTH, ind);
+        for (const auto &e : rot) {
+            if (e.first == ind[0] || e.first == ind[1] || e.first == ind[2]) continue;
+            if (matches12[e.second] >= 0) { matches12[e.second] = -1; nm--; }
+        }
+    }
+    for (int i1 = 0; i1 < n1; i1++)                  // :513-516
+        if (matches12[i1] >= 0) { prev_matched[2 * i1] = kps2[matches12[i1]].x; prev_matched[2 * i1 + 1] = kps2[matches12[i1]].y; }
+    *nmatches = nm;
     return ORBX_OK;
 }

@@ -1373,3 +1373,62 @@ void oro_image_bounds(int width, int height, float fx, float fy, float cx, float
         bounds[0] = 0.0f; bounds[1] = (float)width; bounds[2] = 0.0f; bounds[3] = (float)height;
     }
 }
+
+/* ---- ORBmatcher::SearchForInitialization, src/ORBmatcher.cc:405-520 ---- */
+int oro_search_for_initialization(const oro_keypoint *kps1, const uint8_t *desc1, int n1,
+                                  const oro_grid *g2, const oro_keypoint *kps2, const uint8_t *desc2, int n2,
+                                  float *prev_matched, int window_size, float nnratio, int check_orientation, int32_t *matches12)
+{
+    int nmatches = 0;
+    int *matched_dist = (int *)malloc(sizeof(int) * (size_t)(n2 > 0 ? n2 : 1));       /* vMatchedDistance :415 */
+    int *matches21 = (int *)malloc(sizeof(int) * (size_t)(n2 > 0 ? n2 : 1));          /* vnMatches21 :416 */
+    int32_t *cand = (int32_t *)malloc(sizeof(int32_t) * (size_t)(n2 > 0 ? n2 : 1));
+    int *rot_bin = (int *)malloc(sizeof(int) * (size_t)(n1 > 0 ? n1 : 1) * 2);         /* rotHist as (bin, i1) in push order */
+    int nrot = 0, hist[30];
+    for (int i = 0; i < 30; i++) hist[i] = 0;
+    for (int i = 0; i < n1; i++) matches12[i] = -1;                                    /* :408 */
+    for (int i = 0; i < n2; i++) { matched_dist[i] = 2147483647; matches21[i] = -1; }
+    for (int i1 = 0; i1 < n1; i1++) {                                                  /* :418 */
+        const int level1 = kps1[i1].octave;
+        if (level1 > 0) continue;                                                      /* :422 */
+        const int nc = oro_features_in_area(g2, kps2, prev_matched[2 * i1], prev_matched[2 * i1 + 1], (float)window_size,
+                                            level1, level1, cand, n2);                 /* :425 */
+        if (nc <= 0) continue;
+        const uint8_t *d1 = desc1 + (size_t)i1 * 32;
+        int bestDist = 2147483647, bestDist2 = 2147483647, bestIdx2 = -1;
+        for (int c = 0; c < nc; c++) {                                                 /* :436 */
+            const int i2 = cand[c];
+            const int dist = oro_descriptor_distance(d1, desc2 + (size_t)i2 * 32);
+            if (matched_dist[i2] <= dist) continue;                                    /* :444 */
+            if (dist < bestDist) { bestDist2 = bestDist; bestDist = dist; bestIdx2 = i2; }
+            else if (dist < bestDist2) bestDist2 = dist;
+        }
+        if (bestDist <= 50) {                                                          /* TH_LOW :459 */
+            if ((float)bestDist < (float)bestDist2 * nnratio) {                        /* :461 */
+                if (matches21[bestIdx2] >= 0) { matches12[matches21[bestIdx2]] = -1; nmatches--; }
+                matches12[i1] = bestIdx2;
+                matches21[bestIdx2] = i1;
+                matched_dist[bestIdx2] = bestDist;
+                nmatches++;
+                if (check_orientation) {
+                    const int bin = oro_rot_bin(kps1[i1].angle, kps2[bestIdx2].angle);
+                    rot_bin[2 * nrot] = bin; rot_bin[2 * nrot + 1] = i1; nrot++;
+                    hist[bin]++;                                                       /* rotHist[bin].size(), stale entries included */
+                }
+            }
+        }
+    }
+    if (check_orientation) {                                                           /* :489-510 */
+        int ind1, ind2, ind3;
+        oro_three_maxima(hist, 30, &ind1, &ind2, &ind3);
+        for (int k = 0; k < nrot; k++) {
+            const int bin = rot_bin[2 * k], idx1 = rot_bin[2 * k + 1];
+            if (bin == ind1 || bin == ind2 || bin == ind3) continue;
+            if (matches12[idx1] >= 0) { matches12[idx1] = -1; nmatches--; }
+        }
+    }
+    for (int i1 = 0; i1 < n1; i1++)                                                    /* :513-516 */
+        if (matches12[i1] >= 0) { prev_matched[2 * i1] = kps2[matches12[i1]].x; prev_matched[2 * i1 + 1] = kps2[matches12[i1]].y; }
+    free(matched_dist); free(matches21); free(cand); free(rot_bin);
+    return nmatches;
+}

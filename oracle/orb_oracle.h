@@ -145,6 +145,11 @@ typedef struct {
  * of OpenCV 3.1.0 (5 fixed-point iterations in double).  xy: n (x, y) float pairs in place; dist = k1 k2 p1 p2 k3. */
 void oro_undistort_points(float *xy, int n, float fx, float fy, float cx, float cy, const float dist[5]);
 void oro_image_bounds(int width, int height, float fx, float fy, float cx, float cy, const float dist[5], float bounds[4]);
+/* ORBmatcher::SearchForInitialization (src/ORBmatcher.cc:405-520) on a grid of frame 2.  prev_matched: n1 (x, y) pairs,
+ * updated in place (:513-516); matches12[n1].  Returns nmatches. */
+int oro_search_for_initialization(const oro_keypoint *kps1, const uint8_t *desc1, int n1,
+                                  const oro_grid *g2, const oro_keypoint *kps2, const uint8_t *desc2, int n2,
+                                  float *prev_matched, int window_size, float nnratio, int check_orientation, int32_t *matches12);
 /* AssignFeaturesToGrid + PosInGrid; items must hold n ints */
 void oro_grid_build(oro_grid *g, const oro_keypoint *kps_un, int n, float min_x, float max_x, float min_y, float max_y, int *items);
 /* GetFeaturesInArea: returns the count written to out (reference order), -1 if cap is too small */

@@ -78,6 +78,8 @@ def lib(native=False):
     L.oro_rot_bin.restype = C.c_int
     L.oro_rot_filter.argtypes = [vp, vp, vp, C.c_int]
     L.oro_rot_filter.restype = C.c_int
+    L.oro_search_for_initialization.argtypes = [vp, vp, C.c_int, vp, vp, vp, C.c_int, vp, C.c_int, C.c_float, C.c_int, vp]
+    L.oro_search_for_initialization.restype = C.c_int
     L.oro_undistort_points.argtypes = [vp, C.c_int, C.c_float, C.c_float, C.c_float, C.c_float, vp]
     L.oro_undistort_points.restype = None
     L.oro_image_bounds.argtypes = [C.c_int, C.c_int, C.c_float, C.c_float, C.c_float, C.c_float, vp, vp]
@@ -252,6 +254,18 @@ class FrameGrid:
         self.L.oro_search_area_best2(C.byref(self.g), _p(self.kps), _p(train_desc), _p(sk) if sk is not None else None,
                                      _p(qdesc), _p(x), _p(y), _p(r), _p(mn), _p(mx), nq, _p(bi), _p(bd), _p(sd))
         return bi, bd, sd
+
+
+def search_for_initialization(kps1, desc1, grid2, desc2, prev_matched, window_size, nnratio, check_ori):
+    """ORBmatcher::SearchForInitialization on the oracle; grid2 = FrameGrid of frame 2; prev_matched (n1, 2) float32 is
+    updated in place.  -> (vnMatches12, nmatches)"""
+    kps1 = np.ascontiguousarray(kps1, KP_DTYPE)
+    desc1 = np.ascontiguousarray(desc1, np.uint8); desc2 = np.ascontiguousarray(desc2, np.uint8)
+    assert prev_matched.dtype == np.float32 and prev_matched.flags["C_CONTIGUOUS"]
+    m12 = np.full(len(kps1), -1, np.int32)
+    n = lib().oro_search_for_initialization(_p(kps1), _p(desc1), len(kps1), C.byref(grid2.g), _p(grid2.kps), _p(desc2), len(grid2.kps),
+                                            _p(prev_matched), int(window_size), nnratio, int(check_ori), _p(m12))
+    return m12, n
 
 
 def stereo_matches(ex, kl, dl, kr, dr, pyrL, pyrR, mb, mbf):

@@ -97,3 +97,36 @@ def test_hip_grid_edge_cases(orbx):
     assert list(off) == [0, 0]
     bi, bd, sd = m.search_area_best2(np.zeros((1, 32), np.uint8), [10.0], [5.0], 6.0, -1, -1, np.zeros((0, 32), np.uint8))
     assert (bi[0], bd[0], sd[0]) == (-1, 256, 256)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("shift,window,ratio,ori", [((7, 3), 100, 0.9, True), ((25, 10), 30, 0.9, True), ((3, 2), 100, 0.6, False),
+                                                      ((40, 0), 50, 1.0, True)])
+def test_search_for_initialization_equals_oracle(orbx, synth, shift, window, ratio, ori):
+    """ORBmatcher::SearchForInitialization (src/ORBmatcher.cc:405-520) as Tracking::MonocularInitialization calls it
+    (Tracking.cc:608-609: ORBmatcher(0.9, true), vbPrevMatched = the initial frame's keypoints, window 100), and a second
+    call that starts from the updated vbPrevMatched like the next frame does."""
+    W, H = 640, 480
+    f0, f1 = synth.frame_pair(11, W, H, shift=shift)
+    ex = orbx.ORBextractor(2000, max_width=W, max_height=H)          # mpIniORBextractor: 2 * nFeatures
+    k0, d0 = ex(f0); k1, d1 = ex(f1)
+    m = orbx.ORBmatcher(ratio, ori, max_queries=4096, max_train=4096, max_pairs=1 << 21)
+    m.grid_build(k1, 0.0, float(W), 0.0, float(H))
+    og = O.FrameGrid(k1, 0.0, float(W), 0.0, float(H))
+    prev = np.ascontiguousarray(np.stack([k0["x"], k0["y"]], 1), np.float32)
+    oprev = prev.copy()
+    m12, nm = m.SearchForInitialization(k0, d0, k1, d1, prev, window)
+    om12, onm = O.search_for_initialization(k0, d0, og, d1, oprev, window, ratio, ori)
+    assert nm == onm and np.array_equal(m12, om12) and np.array_equal(prev, oprev)
+    assert nm == int((m12 >= 0).sum()) and (k0["octave"][m12 >= 0] == 0).all()
+    if window >= 50 and ratio >= 0.9:
+        assert nm > 50
+    sel = m12 >= 0
+    assert len(np.unique(m12[sel])) == sel.sum()                         # vnMatches21 keeps the matching one-to-one
+    # second round from the updated vbPrevMatched
+    m12b, nmb = m.SearchForInitialization(k0, d0, k1, d1, prev, window)
+    om12b, onmb = O.search_for_initialization(k0, d0, og, d1, oprev, window, ratio, ori)
+    assert nmb == onmb and np.array_equal(m12b, om12b) and np.array_equal(prev, oprev)
+    # degenerate: no keypoints in frame 1
+    e12, en = m.SearchForInitialization(k0[:0], d0[:0], k1, d1, prev[:0].copy(), window)
+    assert en == 0 and len(e12) == 0
