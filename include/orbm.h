@@ -113,6 +113,27 @@ int orbm_search_for_initialization(orbm_matcher *m, const orbx_keypoint *kps1, c
                                    int32_t *matches12, int *nmatches);
 
 /*
+ * ORBmatcher::SearchByProjection(Frame &CurrentFrame, const Frame &LastFrame, th, bMono) (src/ORBmatcher.cc:1328-1470), the
+ * matcher of Tracking::TrackWithMotionModel.  The current frame's grid must be in the handle (orbm_grid_build on its mvKeysUn).
+ *   last frame, per feature i:  has_point[i] = pMP && !mvbOutlier[i];  xw = pMP->GetWorldPos();  mp_desc = pMP->GetDescriptor();
+ *                               mp_obs[i] = pMP->Observations();  kps_last[i] = octave of mvKeys[i], angle of mvKeysUn[i]
+ *   current frame:              Tcw / Tlw = CurrentFrame.mTcw / LastFrame.mTcw (row-major 4x4 float);  bounds = mnMinX, mnMaxX,
+ *                               mnMinY, mnMaxY;  scale_factors = mvScaleFactors;  u_right = mvuRight or NULL
+ *   cur_obs[i2]   in/out: -1 where mvpMapPoints[i2] is NULL, else that point's Observations() (> 0 keeps its place, :1403-1405)
+ *   cur_match[i2] out: the last-frame feature whose MapPoint this call put into mvpMapPoints[i2], or -1
+ * The projections (cv::Mat algebra = OpenCV's float GEMM: double accumulation, one rounding) run on the host, all windows and
+ * all candidate distances in two GPU passes, and the scan on the host: it is sequential in the reference (an assignment
+ * blocks or is overwritten by later ones; *nmatches counts assignments, the rotation cull decrements once per histogram
+ * entry, exactly as :1428-1429 and :1458-1462 do).
+ */
+int orbm_search_by_projection_last(orbm_matcher *m, int n_last, const uint8_t *has_point, const float *xw, const uint8_t *mp_desc,
+                                   const int32_t *mp_obs, const orbx_keypoint *kps_last, const float *Tcw, const float *Tlw,
+                                   float fx, float fy, float cx, float cy, float mb, float mbf, const float bounds[4],
+                                   const float *scale_factors, int nlevels, const orbx_keypoint *kps_cur, const uint8_t *desc_cur,
+                                   const float *u_right, int n_cur, float th, int mono, int check_orientation,
+                                   int32_t *cur_obs, int32_t *cur_match, int *nmatches);
+
+/*
  * Frame::UndistortKeyPoints (src/Frame.cc:404-434) and Frame::ComputeImageBounds (:436-463): host code, they run once per
  * frame on ~10^3 points between orbx_extract and orbm_grid_build.  dist = mDistCoef (k1, k2, p1, p2[, k3]); ndist = 4 or 5.
  * With dist[0] == 0 both are the identity exactly as in the reference (:406-410, :455-461).  Otherwise the points go

@@ -161,6 +161,9 @@ def _bind_matcher(L):
     L.orbm_three_maxima.argtypes = [vp, C.c_int, vp]
     L.orbm_search_for_initialization.argtypes = [vp, vp, vp, C.c_int, vp, vp, C.c_int, vp, C.c_int, C.c_float, C.c_int, vp, vp]
     L.orbm_search_for_initialization.restype = C.c_int
+    L.orbm_search_by_projection_last.argtypes = [vp, C.c_int, vp, vp, vp, vp, vp, vp, vp, C.c_float, C.c_float, C.c_float, C.c_float,
+                                                 C.c_float, C.c_float, vp, vp, C.c_int, vp, vp, vp, C.c_int, C.c_float, C.c_int, C.c_int, vp, vp, vp]
+    L.orbm_search_by_projection_last.restype = C.c_int
     L.orbm_undistort_keypoints.argtypes = [vp, C.c_int, C.c_float, C.c_float, C.c_float, C.c_float, vp, C.c_int, vp]
     L.orbm_undistort_keypoints.restype = C.c_int
     L.orbm_image_bounds.argtypes = [C.c_int, C.c_int, C.c_float, C.c_float, C.c_float, C.c_float, vp, C.c_int, vp]
@@ -433,6 +436,26 @@ class ORBmatcher:
         _mchk(self.L.orbm_search_area_best2(self.h, _p(qdesc), _p(x), _p(y), _p(r), _p(mn), _p(mx), nq, _p(train_desc), _p(skip),
                                             _p(bi), _p(bd), _p(sd)))
         return bi, bd, sd
+
+    def SearchByProjectionLast(self, has_point, xw, mp_desc, mp_obs, kps_last, Tcw, Tlw, K, mb, mbf, bounds, scale_factors,
+                               kps_cur, desc_cur, cur_obs, th, mono, u_right=None):
+        """ORBmatcher::SearchByProjection(Frame &CurrentFrame, const Frame &LastFrame, th, bMono) (src/ORBmatcher.cc:1328-1470);
+        arguments as in include/orbm.h.  cur_obs (int32, in/out).  Returns (cur_match, nmatches)."""
+        has_point = np.ascontiguousarray(has_point, np.uint8); xw = np.ascontiguousarray(xw, np.float32).reshape(-1, 3)
+        mp_desc = np.ascontiguousarray(mp_desc, np.uint8).reshape(-1, 32); mp_obs = np.ascontiguousarray(mp_obs, np.int32)
+        kps_last = np.ascontiguousarray(kps_last); kps_cur = np.ascontiguousarray(kps_cur)
+        desc_cur = np.ascontiguousarray(desc_cur, np.uint8).reshape(-1, 32)
+        Tcw = np.ascontiguousarray(Tcw, np.float32).reshape(16); Tlw = np.ascontiguousarray(Tlw, np.float32).reshape(16)
+        b = np.ascontiguousarray(bounds, np.float32); sf = np.ascontiguousarray(scale_factors, np.float32)
+        ur = None if u_right is None else np.ascontiguousarray(u_right, np.float32)
+        assert cur_obs.dtype == np.int32 and cur_obs.flags["C_CONTIGUOUS"] and len(cur_obs) == len(kps_cur)
+        cm = np.full(len(kps_cur), -1, np.int32)
+        nm = C.c_int(0)
+        fx, fy, cx, cy = K
+        _mchk(self.L.orbm_search_by_projection_last(self.h, len(kps_last), _p(has_point), _p(xw), _p(mp_desc), _p(mp_obs), _p(kps_last), _p(Tcw), _p(Tlw),
+                                                    fx, fy, cx, cy, mb, mbf, _p(b), _p(sf), len(sf), _p(kps_cur), _p(desc_cur), _p(ur), len(kps_cur),
+                                                    th, int(mono), 1 if self.mbCheckOrientation else 0, _p(cur_obs), _p(cm), C.byref(nm)))
+        return cm, nm.value
 
     def SearchForInitialization(self, kps1, desc1, kps2, desc2, prev_matched, windowSize=10):
         """ORBmatcher::SearchForInitialization(F1, F2, vbPrevMatched, vnMatches12, windowSize) (src/ORBmatcher.cc:405-520).

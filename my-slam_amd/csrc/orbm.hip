@@ -258,6 +258,13 @@ __global__ __launch_bounds__(M_THREADS) void k_dist_csr(
     dist[c] = hamming256(Q[0], Q[1], Tj[0], Tj[1]);
 }
 
+void orbm_launch_dist_csr(const uint8_t *d_q, int nq, const uint8_t *d_t, const int32_t *d_off, const int32_t *d_idx, int total,
+                          int32_t *d_dist, hipStream_t s)
+{
+    if (total > 0)
+        hipLaunchKernelGGL(k_dist_csr, dim3((unsigned)((total + M_THREADS - 1) / M_THREADS)), dim3(M_THREADS), 0, s, d_q, nq, d_t, d_off, d_idx, total, d_dist);
+}
+
 // pairs given explicitly as (query << 16 | train), both below 65536: no per-thread binary search over off[]
 __global__ __launch_bounds__(M_THREADS) void k_dist_pairs16(const uint8_t *__restrict__ q, const uint8_t *__restrict__ t,
                                                             const uint32_t *__restrict__ pairs, int total, int32_t *__restrict__ dist)

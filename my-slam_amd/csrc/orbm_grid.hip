@@ -438,6 +438,68 @@ extern "C" int orbm_search_area_best2(orbm_matcher *m, const uint8_t *qdesc, con
     return ORBX_OK;
 }
 
+// GetFeaturesInArea for nq windows AND the distance of every candidate to its window's descriptor, for the matchers whose scan
+// is sequential on the host (SearchForInitialization, SearchByProjection(Frame, Frame)): inputs go up in one copy, counts come
+// back, offsets go up, lists and distances come back -- two synchronisations.  (One pass into fixed per-window slots was
+// measured: the fullest windows need > 128 slots, and copying nq x slots back costs more than the second round trip.)
+// Falls back to the two public calls when the arena has no room yet (first call).
+static int area_pairs(orbm_matcher *m, const float *x, const float *y, const float *r, const int32_t *mn, const int32_t *mx, int nq,
+                      const uint8_t *qdesc, const uint8_t *train_desc, int n_train,
+                      std::vector<int32_t> &off, std::vector<int32_t> &idx, std::vector<int32_t> &dist)
+{
+    off.assign((size_t)nq + 1, 0);
+    MHIPCHK(hipSetDevice(m->device));
+    { int rc_ = orbm_arena_begin(m); if (rc_ != ORBX_OK) return rc_; }
+    { int rc_ = ensure_query_staging(m, (size_t)nq); if (rc_ != ORBX_OK) return rc_; }
+    hipStream_t s = m->stream;
+    const size_t nb4 = (size_t)nq * 4, mark = m->arena_used;
+    const float *sx = (const float *)orbm_stage_in(m, x, nb4), *sy = (const float *)orbm_stage_in(m, y, nb4), *sr = (const float *)orbm_stage_in(m, r, nb4);
+    const int32_t *smn = (const int32_t *)orbm_stage_in(m, mn, nb4), *smx = (const int32_t *)orbm_stage_in(m, mx, nb4);
+    const uint8_t *sq = (const uint8_t *)orbm_stage_in(m, qdesc, (size_t)nq * 32), *st = (const uint8_t *)orbm_stage_in(m, train_desc, (size_t)n_train * 32);
+    int32_t *soff = (int32_t *)orbm_stage_in(m, off.data(), ((size_t)nq + 1) * 4);      // place holder, filled after the counts are known
+    if (!(sx && sy && sr && smn && smx && sq && st && soff)) {
+        idx.assign((size_t)std::max<long long>(std::min<long long>(m->max_pairs, (long long)nq * n_train), 1), 0);
+        const int total = orbm_features_in_area(m, x, y, r, mn, mx, nq, off.data(), idx.data(), (int)idx.size());
+        if (total < 0) return total;
+        idx.resize((size_t)std::max(total, 1));
+        dist.assign((size_t)std::max(total, 1), 0);
+        if (total > 0) { int rc = orbm_distances(m, qdesc, nq, train_desc, n_train, off.data(), idx.data(), dist.data()); if (rc != ORBX_OK) return rc; }
+        return total;
+    }
+    { int rc_ = orbm_flush_in(m, mark, s); if (rc_ != ORBX_OK) return rc_; }
+    const size_t Q = m->qf_elems;
+    int32_t *d_cnt = m->d_qi + 2 * Q;
+    const dim3 grid((nq + 3) / 4);
+    hipLaunchKernelGGL(k_area_list<0>, grid, dim3(M_THREADS), 0, s, m->grid, sx, sy, sr, smn, smx, nq, d_cnt, (const int32_t *)nullptr, (int32_t *)nullptr);
+    MHIPCHK(hipGetLastError());
+    const int32_t *cnt = (const int32_t *)orbm_d2h_tmp(m, d_cnt, nb4, s);
+    if (!cnt) return mfail(ORBX_E_HIP, "staging arena exhausted");
+    { int rc_ = orbm_sync(m, s); if (rc_ != ORBX_OK) return rc_; }
+    for (int i = 0; i < nq; i++) off[i + 1] = off[i] + cnt[i];
+    const int total = off[nq];
+    idx.assign((size_t)std::max(total, 1), 0); dist.assign((size_t)std::max(total, 1), 0);
+    if (total == 0) return 0;
+    if (total > m->max_pairs) return mfail(ORBX_E_CAPACITY, "%d candidates, matcher sized for %d pairs", total, m->max_pairs);
+    uint8_t *h_off = m->arena + ((uint8_t *)soff - m->d_arena);
+    memcpy(h_off, off.data(), ((size_t)nq + 1) * 4);
+    MHIPCHK(hipMemcpyAsync(soff, h_off, ((size_t)nq + 1) * 4, hipMemcpyHostToDevice, s));
+    hipLaunchKernelGGL(k_area_list<1>, grid, dim3(M_THREADS), 0, s, m->grid, sx, sy, sr, smn, smx, nq, (int32_t *)nullptr, (const int32_t *)soff, m->d_idx);
+    MHIPCHK(hipGetLastError());
+    orbm_launch_dist_csr(sq, nq, st, soff, m->d_idx, total, m->d_out, s);
+    MHIPCHK(hipGetLastError());
+    const void *hi = orbm_d2h_tmp(m, m->d_idx, (size_t)total * 4, s), *hd = orbm_d2h_tmp(m, m->d_out, (size_t)total * 4, s);
+    if (!hi || !hd) {     // no room for the lists this call (the arena grows for the next one): plain copies
+        MHIPCHK(hipMemcpyAsync(idx.data(), m->d_idx, (size_t)total * 4, hipMemcpyDeviceToHost, s));
+        MHIPCHK(hipMemcpyAsync(dist.data(), m->d_out, (size_t)total * 4, hipMemcpyDeviceToHost, s));
+        MHIPCHK(hipStreamSynchronize(s));
+        return total;
+    }
+    { int rc_ = orbm_sync(m, s); if (rc_ != ORBX_OK) return rc_; }
+    memcpy(idx.data(), hi, (size_t)total * 4);
+    memcpy(dist.data(), hd, (size_t)total * 4);
+    return total;
+}
+
 // ---- ORBmatcher::SearchForInitialization (src/ORBmatcher.cc:405-520) ----
 extern "C" int orbm_search_for_initialization(orbm_matcher *m, const orbx_keypoint *kps1, const uint8_t *desc1, int n1,
                                               const orbx_keypoint *kps2, const uint8_t *desc2, int n2,
@@ -459,20 +521,15 @@ extern "C" int orbm_search_for_initialization(orbm_matcher *m, const orbx_keypoi
     if (nq == 0) return ORBX_OK;
     if (nq > m->max_q) return mfail(ORBX_E_CAPACITY, "%d level-0 keypoints, matcher sized for %d queries", nq, m->max_q);
     std::vector<float> x(nq), y(nq), r(nq, (float)window_size);
-    std::vector<int32_t> lv(nq), off((size_t)nq + 1), idx((size_t)std::max<long long>(std::min<long long>(m->max_pairs, (long long)nq * n2), 1));
+    std::vector<int32_t> lv(nq), off, idx, dist;
     std::vector<uint8_t> qd((size_t)nq * 32);
     for (int k = 0; k < nq; k++) {
         const int i = qi[k];
         x[k] = prev_matched[2 * i]; y[k] = prev_matched[2 * i + 1]; lv[k] = kps1[i].octave;
         memcpy(&qd[(size_t)k * 32], desc1 + (size_t)i * 32, 32);
     }
-    const int total = orbm_features_in_area(m, x.data(), y.data(), r.data(), lv.data(), lv.data(), nq, off.data(), idx.data(), (int)idx.size());
+    const int total = area_pairs(m, x.data(), y.data(), r.data(), lv.data(), lv.data(), nq, qd.data(), desc2, n2, off, idx, dist);
     if (total < 0) return total;
-    std::vector<int32_t> dist((size_t)std::max(total, 1));
-    if (total > 0) {
-        int rc = orbm_distances(m, qd.data(), nq, desc2, n2, off.data(), idx.data(), dist.data());
-        if (rc != ORBX_OK) return rc;
-    }
     // the sequential scan (:418-487)
     std::vector<int> matched_dist((size_t)n2, INT_MAX), matches21((size_t)n2, -1);
     std::vector<std::pair<int, int>> rot;           // rotHist as (bin, i1) in push order
@@ -516,6 +573,108 @@ extern "C" int orbm_search_for_initialization(orbm_matcher *m, const orbx_keypoi
     }
     for (int i1 = 0; i1 < n1; i1++)                  // :513-516
         if (matches12[i1] >= 0) { prev_matched[2 * i1] = kps2[matches12[i1]].x; prev_matched[2 * i1 + 1] = kps2[matches12[i1]].y; }
+    *nmatches = nm;
+    return ORBX_OK;
+}
+
+// ---- ORBmatcher::SearchByProjection(Frame&, const Frame&, th, bMono) (src/ORBmatcher.cc:1328-1470) ----
+static inline float gemm_row(const float *T, int row, const float *x)      // (R x + t)[row] as OpenCV's float GEMM: double sum, one rounding
+{
+    const double s = (double)T[4 * row] * x[0] + (double)T[4 * row + 1] * x[1] + (double)T[4 * row + 2] * x[2];
+    return (float)(s + (double)T[4 * row + 3]);
+}
+extern "C" int orbm_search_by_projection_last(orbm_matcher *m, int n_last, const uint8_t *has_point, const float *xw, const uint8_t *mp_desc,
+                                              const int32_t *mp_obs, const orbx_keypoint *kps_last, const float *Tcw, const float *Tlw,
+                                              float fx, float fy, float cx, float cy, float mb, float mbf, const float bounds[4],
+                                              const float *scale_factors, int nlevels, const orbx_keypoint *kps_cur, const uint8_t *desc_cur,
+                                              const float *u_right, int n_cur, float th, int mono, int check_orientation,
+                                              int32_t *cur_obs, int32_t *cur_match, int *nmatches)
+{
+    if (!m) return mfail(ORBX_E_INVALID, "NULL handle");
+    if (n_last < 0 || n_cur < 0 || !Tcw || !Tlw || !bounds || !scale_factors || nlevels < 1 || !nmatches ||
+        (n_last > 0 && (!has_point || !xw || !mp_desc || !mp_obs || !kps_last)) || (n_cur > 0 && (!kps_cur || !desc_cur || !cur_obs || !cur_match)))
+        return mfail(ORBX_E_INVALID, "bad argument");
+    *nmatches = 0;
+    for (int i = 0; i < n_cur; i++) cur_match[i] = -1;
+    if (n_last == 0 || n_cur == 0) return ORBX_OK;
+    if (!m->grid_ok || m->grid.n != n_cur) return mfail(ORBX_E_INVALID, "orbm_grid_build(current frame) has not been called");
+    float twc[3];                                   // :1342-1350
+    for (int k = 0; k < 3; k++)
+        twc[k] = (float)((double)(-Tcw[k]) * Tcw[3] + (double)(-Tcw[4 + k]) * Tcw[7] + (double)(-Tcw[8 + k]) * Tcw[11]);
+    const float tlc2 = gemm_row(Tlw, 2, twc);
+    const bool forward = tlc2 > mb && !mono, backward = -tlc2 > mb && !mono;
+    // projections (:1352-1394): one window per last-frame feature that survives the checks
+    struct Qr { int i; float u, invzc, radius; };
+    std::vector<Qr> qs;
+    std::vector<float> x, y, r;
+    std::vector<int32_t> mn, mx;
+    for (int i = 0; i < n_last; i++) {
+        if (!has_point[i]) continue;
+        const float *X = xw + 3 * (size_t)i;
+        const float xc = gemm_row(Tcw, 0, X), yc = gemm_row(Tcw, 1, X), zc = gemm_row(Tcw, 2, X);
+        const float invzc = (float)(1.0 / zc);
+        if (invzc < 0) continue;
+        const float u = fx * xc * invzc + cx, v = fy * yc * invzc + cy;
+        if (u < bounds[0] || u > bounds[1]) continue;
+        if (v < bounds[2] || v > bounds[3]) continue;
+        const int oct = kps_last[i].octave;
+        if (oct < 0 || oct >= nlevels) return mfail(ORBX_E_INVALID, "last-frame keypoint %d on octave %d of %d", i, oct, nlevels);
+        const float radius = th * scale_factors[oct];
+        qs.push_back({i, u, invzc, radius});
+        x.push_back(u); y.push_back(v); r.push_back(radius);
+        if (forward) { mn.push_back(oct); mx.push_back(-1); }
+        else if (backward) { mn.push_back(0); mx.push_back(oct); }
+        else { mn.push_back(oct - 1); mx.push_back(oct + 1); }
+    }
+    const int nq = (int)qs.size();
+    if (nq == 0) return ORBX_OK;
+    if (nq > m->max_q) return mfail(ORBX_E_CAPACITY, "%d projected points, matcher sized for %d queries", nq, m->max_q);
+    std::vector<int32_t> off, idx, dist;
+    std::vector<uint8_t> qd((size_t)nq * 32);
+    for (int k = 0; k < nq; k++) memcpy(&qd[(size_t)k * 32], mp_desc + (size_t)qs[k].i * 32, 32);
+    const int total = area_pairs(m, x.data(), y.data(), r.data(), mn.data(), mx.data(), nq, qd.data(), desc_cur, n_cur, off, idx, dist);
+    if (total < 0) return total;
+    // the sequential scan (:1396-1444)
+    std::vector<std::pair<int, int>> rot;
+    int32_t hist[ORBM_HISTO_LENGTH] = {0};
+    const float factor = 1.0f / ORBM_HISTO_LENGTH;
+    int nm = 0;
+    for (int k = 0; k < nq; k++) {
+        if (off[k + 1] == off[k]) continue;
+        const Qr &q = qs[k];
+        int bestDist = 256, bestIdx2 = -1;
+        for (int c = off[k]; c < off[k + 1]; c++) {
+            const int i2 = idx[c];
+            if (cur_obs[i2] > 0) continue;
+            if (u_right && u_right[i2] > 0) {
+                const float ur = q.u - mbf * q.invzc;
+                const float er = fabsf(ur - u_right[i2]);
+                if (er > q.radius) continue;
+            }
+            const int d = dist[c];
+            if (d < bestDist) { bestDist = d; bestIdx2 = i2; }
+        }
+        if (bestDist <= ORBM_TH_HIGH) {
+            cur_obs[bestIdx2] = mp_obs[q.i];
+            cur_match[bestIdx2] = q.i;
+            nm++;
+            if (check_orientation) {
+                float rot_ = kps_last[q.i].angle - kps_cur[bestIdx2].angle;
+                if (rot_ < 0.0) rot_ += 360.0f;
+                int bin = (int)roundf(rot_ * factor);
+                if (bin == ORBM_HISTO_LENGTH) bin = 0;
+                if (bin < 0 || bin >= ORBM_HISTO_LENGTH) return mfail(ORBX_E_INVALID, "keypoint angle outside [0, 360)");
+                rot.emplace_back(bin, bestIdx2);
+                hist[bin]++;
+            }
+        }
+    }
+    if (check_orientation) {                         // :1447-1466
+        int32_t ind[3];
+        orbm_three_maxima(hist, ORBM_HISTO_LENGTH, ind);
+        for (const auto &e : rot)
+            if (e.first != ind[0] && e.first != ind[1] && e.first != ind[2]) { cur_obs[e.second] = -1; cur_match[e.second] = -1; nm--; }
+    }
     *nmatches = nm;
     return ORBX_OK;
 }

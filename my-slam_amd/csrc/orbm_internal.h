@@ -62,6 +62,9 @@ int orbm_arena_begin(orbm_matcher *m);                                          
 int orbm_h2d(orbm_matcher *m, void *dev, const void *host, size_t bytes, hipStream_t s);   // staged host -> device copy
 int orbm_d2h(orbm_matcher *m, void *host, const void *dev, size_t bytes, hipStream_t s);   // staged; lands in host at orbm_sync()
 int orbm_sync(orbm_matcher *m, hipStream_t s);
+// k_dist_csr (orbm.hip) for callers in other files: dist[c] of every CSR candidate, off has nq + 1 entries
+void orbm_launch_dist_csr(const uint8_t *d_q, int nq, const uint8_t *d_t, const int32_t *d_off, const int32_t *d_idx, int total,
+                          int32_t *d_dist, hipStream_t s);
 // Staged input: copies into the pinned arena and returns where it will be in the device mirror after orbm_flush_in()
 // (every hipMemcpyAsync costs ~7 us of host time, so the inputs of one call travel together).  NULL: no room this call.
 void *orbm_stage_in(orbm_matcher *m, const void *host, size_t bytes);

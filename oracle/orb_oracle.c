@@ -1432,3 +1432,82 @@ int oro_search_for_initialization(const oro_keypoint *kps1, const uint8_t *desc1
     free(matched_dist); free(matches21); free(cand); free(rot_bin);
     return nmatches;
 }
+
+/* ---- ORBmatcher::SearchByProjection(Frame&, const Frame&, th, bMono), src/ORBmatcher.cc:1328-1470 ---- */
+static float oro_gemm_row(const float *T, int row, const float *x)      /* (R x + t)[row]: double accumulation, one rounding */
+{
+    const double s = (double)T[4 * row] * x[0] + (double)T[4 * row + 1] * x[1] + (double)T[4 * row + 2] * x[2];
+    return (float)(s + (double)T[4 * row + 3]);
+}
+int oro_search_by_projection_last(int n_last, const uint8_t *has_point, const float *xw, const uint8_t *mp_desc, const int32_t *mp_obs,
+                                  const oro_keypoint *kps_last, const float *Tcw, const float *Tlw,
+                                  float fx, float fy, float cx, float cy, float mb, float mbf, const float bounds[4],
+                                  const float *scale_factors, const oro_grid *g, const oro_keypoint *kps_cur, const uint8_t *desc_cur,
+                                  const float *u_right, int n_cur, float th, int mono, int check_orientation,
+                                  int32_t *cur_obs, int32_t *cur_match)
+{
+    int nmatches = 0, nrot = 0, cap_rot = n_last > 0 ? n_last : 1, hist[30];
+    int *rot = (int *)malloc(sizeof(int) * 2 * (size_t)cap_rot);      /* rotHist as (bin, bestIdx2) in push order */
+    int32_t *cand = (int32_t *)malloc(sizeof(int32_t) * (size_t)(n_cur > 0 ? n_cur : 1));
+    for (int i = 0; i < 30; i++) hist[i] = 0;
+    for (int i = 0; i < n_cur; i++) cur_match[i] = -1;
+    /* twc = -Rcw^T tcw (:1342); tlc = Rlw twc + tlw (:1347): only the z component is used */
+    float twc[3], tlc2;
+    for (int k = 0; k < 3; k++) {
+        const double s = (double)(-Tcw[k]) * Tcw[3] + (double)(-Tcw[4 + k]) * Tcw[7] + (double)(-Tcw[8 + k]) * Tcw[11];
+        twc[k] = (float)s;
+    }
+    tlc2 = oro_gemm_row(Tlw, 2, twc);
+    const int forward = tlc2 > mb && !mono, backward = -tlc2 > mb && !mono;     /* :1349-1350 */
+    for (int i = 0; i < n_last; i++) {
+        if (!has_point[i]) continue;                                   /* :1356-1358 */
+        const float *X = xw + 3 * (size_t)i;
+        const float xc = oro_gemm_row(Tcw, 0, X), yc = oro_gemm_row(Tcw, 1, X), zc = oro_gemm_row(Tcw, 2, X);
+        const float invzc = (float)(1.0 / zc);                         /* :1366 */
+        if (invzc < 0) continue;
+        const float u = fx * xc * invzc + cx, v = fy * yc * invzc + cy;
+        if (u < bounds[0] || u > bounds[1]) continue;
+        if (v < bounds[2] || v > bounds[3]) continue;
+        const int nLastOctave = kps_last[i].octave;
+        const float radius = th * scale_factors[nLastOctave];          /* :1381 */
+        int nc;
+        if (forward) nc = oro_features_in_area(g, kps_cur, u, v, radius, nLastOctave, -1, cand, n_cur);
+        else if (backward) nc = oro_features_in_area(g, kps_cur, u, v, radius, 0, nLastOctave, cand, n_cur);
+        else nc = oro_features_in_area(g, kps_cur, u, v, radius, nLastOctave - 1, nLastOctave + 1, cand, n_cur);
+        if (nc <= 0) continue;
+        const uint8_t *dMP = mp_desc + (size_t)i * 32;
+        int bestDist = 256, bestIdx2 = -1;
+        for (int c = 0; c < nc; c++) {                                 /* :1400 */
+            const int i2 = cand[c];
+            if (cur_obs[i2] > 0) continue;                             /* a point with observations keeps its place :1403-1405 */
+            if (u_right && u_right[i2] > 0) {                          /* :1407-1413 */
+                const float ur = u - mbf * invzc;
+                const float er = fabsf(ur - u_right[i2]);
+                if (er > radius) continue;
+            }
+            const int dist = oro_descriptor_distance(dMP, desc_cur + (size_t)i2 * 32);
+            if (dist < bestDist) { bestDist = dist; bestIdx2 = i2; }
+        }
+        if (bestDist <= 100) {                                         /* TH_HIGH :1426 */
+            cur_obs[bestIdx2] = mp_obs[i];
+            cur_match[bestIdx2] = i;
+            nmatches++;
+            if (check_orientation) {
+                const int bin = oro_rot_bin(kps_last[i].angle, kps_cur[bestIdx2].angle);
+                if (nrot == cap_rot) { cap_rot *= 2; rot = (int *)realloc(rot, sizeof(int) * 2 * (size_t)cap_rot); }
+                rot[2 * nrot] = bin; rot[2 * nrot + 1] = bestIdx2; nrot++;
+                hist[bin]++;
+            }
+        }
+    }
+    if (check_orientation) {                                           /* :1447-1466: one decrement per entry, even for a repeated i2 */
+        int ind1, ind2, ind3;
+        oro_three_maxima(hist, 30, &ind1, &ind2, &ind3);
+        for (int k = 0; k < nrot; k++) {
+            const int bin = rot[2 * k];
+            if (bin != ind1 && bin != ind2 && bin != ind3) { cur_obs[rot[2 * k + 1]] = -1; cur_match[rot[2 * k + 1]] = -1; nmatches--; }
+        }
+    }
+    free(rot); free(cand);
+    return nmatches;
+}

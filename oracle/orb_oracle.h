@@ -150,6 +150,18 @@ void oro_image_bounds(int width, int height, float fx, float fy, float cx, float
 int oro_search_for_initialization(const oro_keypoint *kps1, const uint8_t *desc1, int n1,
                                   const oro_grid *g2, const oro_keypoint *kps2, const uint8_t *desc2, int n2,
                                   float *prev_matched, int window_size, float nnratio, int check_orientation, int32_t *matches12);
+/* ORBmatcher::SearchByProjection(Frame &CurrentFrame, const Frame &LastFrame, th, bMono) (src/ORBmatcher.cc:1328-1470), the
+ * matcher of TrackWithMotionModel.  Last frame, per feature i: has_point = pMP && !mvbOutlier[i], xw = GetWorldPos(),
+ * mp_desc = GetDescriptor(), mp_obs = Observations(), kps_last = mvKeys/mvKeysUn (octave, angle).  Current frame: poses as
+ * row-major 4x4 float, grid g of kps_cur (mvKeysUn), u_right = mvuRight or NULL, cur_obs[i2] = -1 for a NULL mvpMapPoints
+ * entry else that point's Observations() (in/out), cur_match[i2] = last-frame feature assigned by this call or -1 (out).
+ * cv::Mat algebra (Rcw * x + tcw) as OpenCV's float GEMM does it: double accumulation, one rounding to float. */
+int oro_search_by_projection_last(int n_last, const uint8_t *has_point, const float *xw, const uint8_t *mp_desc, const int32_t *mp_obs,
+                                  const oro_keypoint *kps_last, const float *Tcw, const float *Tlw,
+                                  float fx, float fy, float cx, float cy, float mb, float mbf, const float bounds[4],
+                                  const float *scale_factors, const oro_grid *g, const oro_keypoint *kps_cur, const uint8_t *desc_cur,
+                                  const float *u_right, int n_cur, float th, int mono, int check_orientation,
+                                  int32_t *cur_obs, int32_t *cur_match);
 /* AssignFeaturesToGrid + PosInGrid; items must hold n ints */
 void oro_grid_build(oro_grid *g, const oro_keypoint *kps_un, int n, float min_x, float max_x, float min_y, float max_y, int *items);
 /* GetFeaturesInArea: returns the count written to out (reference order), -1 if cap is too small */

@@ -80,6 +80,9 @@ def lib(native=False):
     L.oro_rot_filter.restype = C.c_int
     L.oro_search_for_initialization.argtypes = [vp, vp, C.c_int, vp, vp, vp, C.c_int, vp, C.c_int, C.c_float, C.c_int, vp]
     L.oro_search_for_initialization.restype = C.c_int
+    L.oro_search_by_projection_last.argtypes = [C.c_int, vp, vp, vp, vp, vp, vp, vp, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float,
+                                                vp, vp, vp, vp, vp, vp, C.c_int, C.c_float, C.c_int, C.c_int, vp, vp]
+    L.oro_search_by_projection_last.restype = C.c_int
     L.oro_undistort_points.argtypes = [vp, C.c_int, C.c_float, C.c_float, C.c_float, C.c_float, vp]
     L.oro_undistort_points.restype = None
     L.oro_image_bounds.argtypes = [C.c_int, C.c_int, C.c_float, C.c_float, C.c_float, C.c_float, vp, vp]
@@ -266,6 +269,23 @@ def search_for_initialization(kps1, desc1, grid2, desc2, prev_matched, window_si
     n = lib().oro_search_for_initialization(_p(kps1), _p(desc1), len(kps1), C.byref(grid2.g), _p(grid2.kps), _p(desc2), len(grid2.kps),
                                             _p(prev_matched), int(window_size), nnratio, int(check_ori), _p(m12))
     return m12, n
+
+
+def search_by_projection_last(has_point, xw, mp_desc, mp_obs, kps_last, Tcw, Tlw, K, mb, mbf, bounds, scale_factors, grid_cur, desc_cur,
+                              cur_obs, th, mono, check_ori, u_right=None):
+    """ORBmatcher::SearchByProjection(CurrentFrame, LastFrame, th, bMono) on the oracle -> (cur_match, nmatches); cur_obs in/out"""
+    has_point = np.ascontiguousarray(has_point, np.uint8); xw = np.ascontiguousarray(xw, np.float32)
+    mp_desc = np.ascontiguousarray(mp_desc, np.uint8); mp_obs = np.ascontiguousarray(mp_obs, np.int32)
+    kps_last = np.ascontiguousarray(kps_last, KP_DTYPE); desc_cur = np.ascontiguousarray(desc_cur, np.uint8)
+    Tcw = np.ascontiguousarray(Tcw, np.float32).reshape(16); Tlw = np.ascontiguousarray(Tlw, np.float32).reshape(16)
+    b = np.ascontiguousarray(bounds, np.float32); sf = np.ascontiguousarray(scale_factors, np.float32)
+    ur = None if u_right is None else np.ascontiguousarray(u_right, np.float32)
+    cm = np.full(len(grid_cur.kps), -1, np.int32)
+    fx, fy, cx, cy = K
+    n = lib().oro_search_by_projection_last(len(kps_last), _p(has_point), _p(xw), _p(mp_desc), _p(mp_obs), _p(kps_last), _p(Tcw), _p(Tlw),
+                                            fx, fy, cx, cy, mb, mbf, _p(b), _p(sf), C.byref(grid_cur.g), _p(grid_cur.kps), _p(desc_cur),
+                                            _p(ur) if ur is not None else None, len(grid_cur.kps), th, int(mono), int(check_ori), _p(cur_obs), _p(cm))
+    return cm, n
 
 
 def stereo_matches(ex, kl, dl, kr, dr, pyrL, pyrR, mb, mbf):

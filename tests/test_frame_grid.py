@@ -130,3 +130,48 @@ def test_search_for_initialization_equals_oracle(orbx, synth, shift, window, rat
     # degenerate: no keypoints in frame 1
     e12, en = m.SearchForInitialization(k0[:0], d0[:0], k1, d1, prev[:0].copy(), window)
     assert en == 0 and len(e12) == 0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mono,th,with_right,dz", [(True, 15.0, False, 0.0), (True, 7.0, False, 0.0), (False, 15.0, True, 0.0),
+                                                    (False, 15.0, True, 0.9), (False, 15.0, True, -0.9)])
+def test_search_by_projection_last_equals_oracle(orbx, synth, mono, th, with_right, dz):
+    """ORBmatcher::SearchByProjection(CurrentFrame, LastFrame, th, bMono) (src/ORBmatcher.cc:1328-1470) as TrackWithMotionModel
+    calls it (Tracking.cc:879-883: ORBmatcher(0.9, true), th 15 or 7), on the three-depth scene: the last frame's MapPoints are
+    its keypoints back-projected to their layer's depth, the current pose is the true one (a camera step along x, for the
+    stereo cases also along z to exercise the forward / backward octave windows and the mvuRight gate)."""
+    W, H = 1241, 376
+    fx, fy, cx, cy, base, shifts = 718.856, 718.856, 607.1928, 185.2157, 0.5, (2, 4, 6)
+    frames, layer = synth.stream_layers(5, W, H, 2, shifts=shifts)
+    ex = orbx.ORBextractor(2000, max_width=W, max_height=H)
+    k0, d0 = ex(frames[0]); k1, d1 = ex(frames[1])
+    sf = ex.GetScaleFactors()
+    Z = (fx * base / np.array(shifts, np.float64))[layer[np.clip(np.rint(k0["y"]).astype(int), 0, H - 1), np.clip(np.rint(k0["x"]).astype(int), 0, W - 1)]]
+    xw = np.stack([(k0["x"] - cx) * Z / fx, (k0["y"] - cy) * Z / fy, Z], 1).astype(np.float32)
+    rng = np.random.default_rng(3)
+    has = (rng.random(len(k0)) < 0.85).astype(np.uint8)                 # some features without a MapPoint / flagged outlier
+    obs = rng.integers(0, 4, len(k0)).astype(np.int32)                  # Observations(): 0 = a temporal point that may be overwritten
+    Tlw = np.eye(4, dtype=np.float32)
+    Tcw = np.eye(4, dtype=np.float32); Tcw[0, 3] = -base; Tcw[2, 3] = -dz
+    mb, mbf = 0.54, 386.1448
+    ur = None
+    if with_right:
+        Zc = (fx * base / np.array(shifts, np.float64))[layer[np.clip(np.rint(k1["y"]).astype(int), 0, H - 1), np.clip(np.rint(k1["x"]).astype(int), 0, W - 1)]]
+        ur = (k1["x"] - mbf / Zc).astype(np.float32)
+        ur[::5] = -1.0                                                  # monocular points
+        ur[1::7] += 40.0                                                # stereo matches that contradict the projection: gated out
+    m = orbx.ORBmatcher(0.9, True, max_queries=4096, max_train=4096, max_pairs=1 << 21)
+    m.grid_build(k1, 0.0, float(W), 0.0, float(H))
+    og = O.FrameGrid(k1, 0.0, float(W), 0.0, float(H))
+    cur0 = np.full(len(k1), -1, np.int32)
+    cur0[::11] = rng.integers(0, 3, len(cur0[::11]))                    # a few entries already hold a point (0 = replaceable)
+    ca, cb = cur0.copy(), cur0.copy()
+    cm, nm = m.SearchByProjectionLast(has, xw, d0, obs, k0, Tcw, Tlw, (fx, fy, cx, cy), mb, mbf, (0.0, W, 0.0, H), sf, k1, d1, ca, th, mono, ur)
+    ocm, onm = O.search_by_projection_last(has, xw, d0, obs, k0, Tcw, Tlw, (fx, fy, cx, cy), mb, mbf, (0.0, W, 0.0, H), sf, og, d1, cb, th, mono, True, ur)
+    assert nm == onm and np.array_equal(cm, ocm) and np.array_equal(ca, cb)
+    assert (has[cm[cm >= 0]] == 1).all()
+    if dz == 0.0:
+        assert nm > 300                                                 # the true pose puts most points on their match
+        good = cm >= 0
+        assert np.median(np.abs(k1["x"][good] - (k0["x"][cm[good]] - np.array(shifts)[layer[np.clip(np.rint(k0["y"][cm[good]]).astype(int), 0, H - 1),
+                                                                                                np.clip(np.rint(k0["x"][cm[good]]).astype(int), 0, W - 1)]]))) < 1.5

@@ -4,7 +4,9 @@
 //     Frame::AssignFeaturesToGrid       -> orbm_grid_build
 //     Frame::ComputeBoW                 -> orbv_transform_features + orbv_bow_vector + orbv_feature_vector
 //     Tracking::TrackReferenceKeyFrame  -> orbm_search_by_bow            (ORBmatcher(0.7, true), src/Tracking.cc:774-779)
-//     Tracking::TrackWithMotionModel    -> orbm_search_area_best2 + orbm_rot_filter   (window 15 * scale, octave +-1, TH_HIGH)
+//     Tracking::TrackWithMotionModel    -> with the pose stages: orbm_search_by_projection_last (ORBmatcher::SearchByProjection(
+//                                          CurrentFrame, LastFrame, 15, mono), src/Tracking.cc:879-883); without them the same
+//                                          windows around the previous positions: orbm_search_area_best2 + orbm_rot_filter
 //     Optimizer::PoseOptimization       -> orbp_pose_optimization        (src/Tracking.cc:783-787: start from the last pose)
 //     Relocalization's PnPsolver        -> orbp_pnp_* (0.99,10,300,4,0.5,5.991; iterate(5)) + orbp_pose_optimization
 //                                          (src/Tracking.cc:1392-1445), run every 8th frame to time it
@@ -75,6 +77,13 @@ int main(int argc, char **argv)
     std::vector<float> obs(2 * cap), is2(cap), xw(3 * cap), s2(cap);
     std::vector<uint8_t> outl(cap), inl(cap);
     double max_err = 0, max_reloc_err = 0;
+    float Tlast[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};
+    std::vector<float> xw_all(3 * cap);
+    std::vector<uint8_t> ones(cap, 1);
+    std::vector<int32_t> one_obs(cap, 1), cur_obs(cap), cur_match(cap);
+    float sfac[8];
+    sfac[0] = 1.f;
+    for (int l = 1; l < 8; l++) sfac[l] = sfac[l - 1] * 1.2f;
     for (int k = 0; k < K; k++) {
         cur.kps.resize(cap); cur.desc.resize((size_t)cap * 32);
         cur.fv_node.resize(cap); cur.fv_off.resize(cap + 1); cur.fv_idx.resize(cap);
@@ -138,9 +147,29 @@ int main(int argc, char **argv)
                     n_reloc++;
                     t_reloc.push_back(now_ms() - tr0);
                 }
+                memcpy(Tlast, Tprev, sizeof Tlast);
                 memcpy(Tprev, T, sizeof T);
             }
             const double t4b = now_ms();
+            if (pose) {
+                // TrackWithMotionModel's matcher proper (src/Tracking.cc:879-883): every keypoint of the last frame carries a
+                // MapPoint (its layer's depth through the last pose), the current pose stands in for the velocity model's
+                // prediction, ORBmatcher(0.9, true).SearchByProjection(CurrentFrame, LastFrame, 15, mono)
+                for (int i = 0; i < prev.n; i++) {
+                    const orbx_keypoint &p = prev.kps[i];
+                    const int px = std::min(std::max((int)lrintf(p.x), 0), W - 1), py = std::min(std::max((int)lrintf(p.y), 0), H - 1);
+                    const double Z = depth[layer[(size_t)py * W + px]];
+                    const double Xc[3] = {(p.x - cx) * Z / fx - Tlast[3], (p.y - cy) * Z / fy - Tlast[7], Z - Tlast[11]};
+                    for (int a = 0; a < 3; a++) xw_all[3 * i + a] = (float)(Tlast[a] * Xc[0] + Tlast[4 + a] * Xc[1] + Tlast[8 + a] * Xc[2]);
+                }
+                std::fill(cur_obs.begin(), cur_obs.end(), -1);
+                const float bounds[4] = {0.f, (float)W, 0.f, (float)H};
+                int nmp = 0;
+                CHK(orbm_search_by_projection_last(mt, prev.n, ones.data(), xw_all.data(), prev.desc.data(), one_obs.data(), prev.kps.data(), Tprev, Tlast,
+                                                   fx, fy, cx, cy, 0.f, 0.f, bounds, sfac, 8, cur.kps.data(), cur.desc.data(), nullptr, cur.n,
+                                                   15.0f, 1, 1, cur_obs.data(), cur_match.data(), &nmp));
+                nm_proj += nmp;
+            } else {
             for (int i = 0; i < prev.n; i++) {           // motion-model windows around the previous positions
                 const orbx_keypoint &p = prev.kps[i];
                 qx[i] = p.x; qy[i] = p.y; qr[i] = 15.0f * powf(1.2f, (float)p.octave);
@@ -151,6 +180,7 @@ int main(int argc, char **argv)
             for (int i = 0; i < prev.n; i++) m12[i] = bd[i] <= ORBM_TH_HIGH ? bi[i] : -1;
             for (int i = 0; i < cur.n; i++) at[i] = cur.kps[i].angle;
             nm_proj += orbm_rot_filter(aq.data(), at.data(), m12.data(), prev.n);
+            }
             const double t5 = now_ms();
             if (k >= 5) {
                 const double d[5] = {t1 - t0, t2 - t1, t3 - t2, t4 - t3, t5 - t4b};
