@@ -134,6 +134,20 @@ int orbm_search_by_projection_last(orbm_matcher *m, int n_last, const uint8_t *h
                                    int32_t *cur_obs, int32_t *cur_match, int *nmatches);
 
 /*
+ * ORBmatcher::SearchByProjection(Frame &F, const vector<MapPoint*> &vpMapPoints, th) (src/ORBmatcher.cc:45-125), the matcher of
+ * Tracking::SearchLocalPoints (every frame, against the local map).  Per MapPoint: in_view = mbTrackInView && !isBad(),
+ * proj_x / proj_y / proj_xr = mTrackProjX / Y / XR (proj_xr may be NULL when u_right is), pred_level = mnTrackScaleLevel,
+ * view_cos = mTrackViewCos (RadiusByViewingCos :127-133), mp_desc = GetDescriptor(), mp_obs = Observations().  Frame side and
+ * the cur_obs / cur_match convention as in orbm_search_by_projection_last (cur_match[i2] = MapPoint index).  Best and
+ * second-best with their octaves, TH_HIGH, and the ratio test only when both sit on the same level (:115-118).
+ */
+int orbm_search_by_projection_map(orbm_matcher *m, int n_mp, const uint8_t *in_view, const float *proj_x, const float *proj_y,
+                                  const float *proj_xr, const int32_t *pred_level, const float *view_cos, const uint8_t *mp_desc,
+                                  const int32_t *mp_obs, const float *scale_factors, int nlevels, const orbx_keypoint *kps_cur,
+                                  const uint8_t *desc_cur, const float *u_right, int n_cur, float th, float nnratio,
+                                  int32_t *cur_obs, int32_t *cur_match, int *nmatches);
+
+/*
  * Frame::UndistortKeyPoints (src/Frame.cc:404-434) and Frame::ComputeImageBounds (:436-463): host code, they run once per
  * frame on ~10^3 points between orbx_extract and orbm_grid_build.  dist = mDistCoef (k1, k2, p1, p2[, k3]); ndist = 4 or 5.
  * With dist[0] == 0 both are the identity exactly as in the reference (:406-410, :455-461).  Otherwise the points go

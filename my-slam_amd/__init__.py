@@ -164,6 +164,9 @@ def _bind_matcher(L):
     L.orbm_search_by_projection_last.argtypes = [vp, C.c_int, vp, vp, vp, vp, vp, vp, vp, C.c_float, C.c_float, C.c_float, C.c_float,
                                                  C.c_float, C.c_float, vp, vp, C.c_int, vp, vp, vp, C.c_int, C.c_float, C.c_int, C.c_int, vp, vp, vp]
     L.orbm_search_by_projection_last.restype = C.c_int
+    L.orbm_search_by_projection_map.argtypes = [vp, C.c_int, vp, vp, vp, vp, vp, vp, vp, vp, vp, C.c_int, vp, vp, vp, C.c_int,
+                                                C.c_float, C.c_float, vp, vp, vp]
+    L.orbm_search_by_projection_map.restype = C.c_int
     L.orbm_undistort_keypoints.argtypes = [vp, C.c_int, C.c_float, C.c_float, C.c_float, C.c_float, vp, C.c_int, vp]
     L.orbm_undistort_keypoints.restype = C.c_int
     L.orbm_image_bounds.argtypes = [C.c_int, C.c_int, C.c_float, C.c_float, C.c_float, C.c_float, vp, C.c_int, vp]
@@ -455,6 +458,23 @@ class ORBmatcher:
         _mchk(self.L.orbm_search_by_projection_last(self.h, len(kps_last), _p(has_point), _p(xw), _p(mp_desc), _p(mp_obs), _p(kps_last), _p(Tcw), _p(Tlw),
                                                     fx, fy, cx, cy, mb, mbf, _p(b), _p(sf), len(sf), _p(kps_cur), _p(desc_cur), _p(ur), len(kps_cur),
                                                     th, int(mono), 1 if self.mbCheckOrientation else 0, _p(cur_obs), _p(cm), C.byref(nm)))
+        return cm, nm.value
+
+    def SearchByProjectionMap(self, in_view, proj_x, proj_y, pred_level, view_cos, mp_desc, mp_obs, scale_factors, kps_cur, desc_cur,
+                              cur_obs, th, proj_xr=None, u_right=None):
+        """ORBmatcher::SearchByProjection(Frame &F, const vector<MapPoint*> &vpMapPoints, th) (src/ORBmatcher.cc:45-125);
+        arguments as in include/orbm.h.  Returns (cur_match, nmatches); cur_obs (int32) is updated in place."""
+        f32 = lambda a: None if a is None else np.ascontiguousarray(a, np.float32)
+        in_view = np.ascontiguousarray(in_view, np.uint8); px, py, pxr, vc = f32(proj_x), f32(proj_y), f32(proj_xr), f32(view_cos)
+        lv = np.ascontiguousarray(pred_level, np.int32); mp_desc = np.ascontiguousarray(mp_desc, np.uint8).reshape(-1, 32)
+        mp_obs = np.ascontiguousarray(mp_obs, np.int32); sf = f32(scale_factors); ur = f32(u_right)
+        kps_cur = np.ascontiguousarray(kps_cur); desc_cur = np.ascontiguousarray(desc_cur, np.uint8).reshape(-1, 32)
+        assert cur_obs.dtype == np.int32 and cur_obs.flags["C_CONTIGUOUS"] and len(cur_obs) == len(kps_cur)
+        cm = np.full(len(kps_cur), -1, np.int32)
+        nm = C.c_int(0)
+        _mchk(self.L.orbm_search_by_projection_map(self.h, len(in_view), _p(in_view), _p(px), _p(py), _p(pxr), _p(lv), _p(vc), _p(mp_desc), _p(mp_obs),
+                                                   _p(sf), len(sf), _p(kps_cur), _p(desc_cur), _p(ur), len(kps_cur), th, C.c_float(self.mfNNratio),
+                                                   _p(cur_obs), _p(cm), C.byref(nm)))
         return cm, nm.value
 
     def SearchForInitialization(self, kps1, desc1, kps2, desc2, prev_matched, windowSize=10):

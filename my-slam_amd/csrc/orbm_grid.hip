@@ -678,3 +678,67 @@ extern "C" int orbm_search_by_projection_last(orbm_matcher *m, int n_last, const
     *nmatches = nm;
     return ORBX_OK;
 }
+
+// ---- ORBmatcher::SearchByProjection(Frame&, const vector<MapPoint*>&, th) (src/ORBmatcher.cc:45-125) ----
+extern "C" int orbm_search_by_projection_map(orbm_matcher *m, int n_mp, const uint8_t *in_view, const float *proj_x, const float *proj_y,
+                                             const float *proj_xr, const int32_t *pred_level, const float *view_cos, const uint8_t *mp_desc,
+                                             const int32_t *mp_obs, const float *scale_factors, int nlevels, const orbx_keypoint *kps_cur,
+                                             const uint8_t *desc_cur, const float *u_right, int n_cur, float th, float nnratio,
+                                             int32_t *cur_obs, int32_t *cur_match, int *nmatches)
+{
+    if (!m) return mfail(ORBX_E_INVALID, "NULL handle");
+    if (n_mp < 0 || n_cur < 0 || !scale_factors || nlevels < 1 || !nmatches || (u_right && !proj_xr) ||
+        (n_mp > 0 && (!in_view || !proj_x || !proj_y || !pred_level || !view_cos || !mp_desc || !mp_obs)) ||
+        (n_cur > 0 && (!kps_cur || !desc_cur || !cur_obs || !cur_match)))
+        return mfail(ORBX_E_INVALID, "bad argument");
+    *nmatches = 0;
+    for (int i = 0; i < n_cur; i++) cur_match[i] = -1;
+    if (n_mp == 0 || n_cur == 0) return ORBX_OK;
+    if (!m->grid_ok || m->grid.n != n_cur) return mfail(ORBX_E_INVALID, "orbm_grid_build(frame) has not been called");
+    const bool bFactor = th != 1.0;
+    std::vector<int> qi;
+    std::vector<float> x, y, r;
+    std::vector<int32_t> mn, mx;
+    for (int i = 0; i < n_mp; i++) {
+        if (!in_view[i]) continue;
+        const int lv = pred_level[i];
+        if (lv < 0 || lv >= nlevels) return mfail(ORBX_E_INVALID, "MapPoint %d predicted on level %d of %d", i, lv, nlevels);
+        float rr = view_cos[i] > 0.998 ? 2.5f : 4.0f;         // RadiusByViewingCos
+        if (bFactor) rr *= th;
+        qi.push_back(i); x.push_back(proj_x[i]); y.push_back(proj_y[i]); r.push_back(rr * scale_factors[lv]);
+        mn.push_back(lv - 1); mx.push_back(lv);
+    }
+    const int nq = (int)qi.size();
+    if (nq == 0) return ORBX_OK;
+    if (nq > m->max_q) return mfail(ORBX_E_CAPACITY, "%d MapPoints in view, matcher sized for %d queries", nq, m->max_q);
+    std::vector<int32_t> off, idx, dist;
+    std::vector<uint8_t> qd((size_t)nq * 32);
+    for (int k = 0; k < nq; k++) memcpy(&qd[(size_t)k * 32], mp_desc + (size_t)qi[k] * 32, 32);
+    const int total = area_pairs(m, x.data(), y.data(), r.data(), mn.data(), mx.data(), nq, qd.data(), desc_cur, n_cur, off, idx, dist);
+    if (total < 0) return total;
+    int nm = 0;
+    for (int k = 0; k < nq; k++) {                  // :73-122
+        if (off[k + 1] == off[k]) continue;
+        const int iMP = qi[k];
+        int bestDist = 256, bestLevel = -1, bestDist2 = 256, bestLevel2 = -1, bestIdx = -1;
+        for (int c = off[k]; c < off[k + 1]; c++) {
+            const int i2 = idx[c];
+            if (cur_obs[i2] > 0) continue;
+            if (u_right && u_right[i2] > 0) {
+                const float er = fabsf(proj_xr[iMP] - u_right[i2]);
+                if (er > r[k]) continue;
+            }
+            const int d = dist[c];
+            if (d < bestDist) { bestDist2 = bestDist; bestDist = d; bestLevel2 = bestLevel; bestLevel = kps_cur[i2].octave; bestIdx = i2; }
+            else if (d < bestDist2) { bestLevel2 = kps_cur[i2].octave; bestDist2 = d; }
+        }
+        if (bestDist <= ORBM_TH_HIGH) {
+            if (bestLevel == bestLevel2 && (float)bestDist > nnratio * (float)bestDist2) continue;
+            cur_obs[bestIdx] = mp_obs[iMP];
+            cur_match[bestIdx] = iMP;
+            nm++;
+        }
+    }
+    *nmatches = nm;
+    return ORBX_OK;
+}

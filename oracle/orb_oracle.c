@@ -1511,3 +1511,48 @@ int oro_search_by_projection_last(int n_last, const uint8_t *has_point, const fl
     free(rot); free(cand);
     return nmatches;
 }
+
+/* ---- ORBmatcher::SearchByProjection(Frame&, const vector<MapPoint*>&, th), src/ORBmatcher.cc:45-125 (+ RadiusByViewingCos :127-133) ---- */
+int oro_search_by_projection_map(int n_mp, const uint8_t *in_view, const float *proj_x, const float *proj_y, const float *proj_xr,
+                                 const int32_t *pred_level, const float *view_cos, const uint8_t *mp_desc, const int32_t *mp_obs,
+                                 const float *scale_factors, const oro_grid *g, const oro_keypoint *kps_cur, const uint8_t *desc_cur,
+                                 const float *u_right, int n_cur, float th, float nnratio, int32_t *cur_obs, int32_t *cur_match)
+{
+    int nmatches = 0;
+    const int bFactor = th != 1.0;                                     /* :49 */
+    int32_t *cand = (int32_t *)malloc(sizeof(int32_t) * (size_t)(n_cur > 0 ? n_cur : 1));
+    for (int i = 0; i < n_cur; i++) cur_match[i] = -1;
+    for (int iMP = 0; iMP < n_mp; iMP++) {
+        if (!in_view[iMP]) continue;                                   /* :54-58 */
+        const int nPredictedLevel = pred_level[iMP];
+        float r = view_cos[iMP] > 0.998 ? 2.5f : 4.0f;                  /* RadiusByViewingCos (double 0.998 against a float) */
+        if (bFactor) r *= th;
+        const float rad = r * scale_factors[nPredictedLevel];
+        const int nc = oro_features_in_area(g, kps_cur, proj_x[iMP], proj_y[iMP], rad, nPredictedLevel - 1, nPredictedLevel, cand, n_cur);
+        if (nc <= 0) continue;
+        const uint8_t *dMP = mp_desc + (size_t)iMP * 32;
+        int bestDist = 256, bestLevel = -1, bestDist2 = 256, bestLevel2 = -1, bestIdx = -1;
+        for (int c = 0; c < nc; c++) {
+            const int idx = cand[c];
+            if (cur_obs[idx] > 0) continue;                            /* :85-87 */
+            if (u_right && u_right[idx] > 0) {                         /* :89-94 */
+                const float er = fabsf(proj_xr[iMP] - u_right[idx]);
+                if (er > rad) continue;
+            }
+            const int dist = oro_descriptor_distance(dMP, desc_cur + (size_t)idx * 32);
+            if (dist < bestDist) {
+                bestDist2 = bestDist; bestDist = dist; bestLevel2 = bestLevel; bestLevel = kps_cur[idx].octave; bestIdx = idx;
+            } else if (dist < bestDist2) {
+                bestLevel2 = kps_cur[idx].octave; bestDist2 = dist;
+            }
+        }
+        if (bestDist <= 100) {                                         /* TH_HIGH :115 */
+            if (bestLevel == bestLevel2 && (float)bestDist > nnratio * (float)bestDist2) continue;
+            cur_obs[bestIdx] = mp_obs[iMP];
+            cur_match[bestIdx] = iMP;
+            nmatches++;
+        }
+    }
+    free(cand);
+    return nmatches;
+}

@@ -162,6 +162,14 @@ int oro_search_by_projection_last(int n_last, const uint8_t *has_point, const fl
                                   const float *scale_factors, const oro_grid *g, const oro_keypoint *kps_cur, const uint8_t *desc_cur,
                                   const float *u_right, int n_cur, float th, int mono, int check_orientation,
                                   int32_t *cur_obs, int32_t *cur_match);
+/* ORBmatcher::SearchByProjection(Frame &F, const vector<MapPoint*> &vpMapPoints, th) (src/ORBmatcher.cc:45-125), the matcher of
+ * Tracking::SearchLocalPoints.  Per MapPoint: in_view = mbTrackInView && !isBad(), proj_x/y/xr = mTrackProjX/Y/XR,
+ * pred_level = mnTrackScaleLevel, view_cos = mTrackViewCos, mp_desc, mp_obs = Observations().  Frame as in
+ * oro_search_by_projection_last (grid of mvKeysUn, u_right or NULL, cur_obs in/out, cur_match out = MapPoint index). */
+int oro_search_by_projection_map(int n_mp, const uint8_t *in_view, const float *proj_x, const float *proj_y, const float *proj_xr,
+                                 const int32_t *pred_level, const float *view_cos, const uint8_t *mp_desc, const int32_t *mp_obs,
+                                 const float *scale_factors, const oro_grid *g, const oro_keypoint *kps_cur, const uint8_t *desc_cur,
+                                 const float *u_right, int n_cur, float th, float nnratio, int32_t *cur_obs, int32_t *cur_match);
 /* AssignFeaturesToGrid + PosInGrid; items must hold n ints */
 void oro_grid_build(oro_grid *g, const oro_keypoint *kps_un, int n, float min_x, float max_x, float min_y, float max_y, int *items);
 /* GetFeaturesInArea: returns the count written to out (reference order), -1 if cap is too small */

@@ -83,6 +83,8 @@ def lib(native=False):
     L.oro_search_by_projection_last.argtypes = [C.c_int, vp, vp, vp, vp, vp, vp, vp, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float,
                                                 vp, vp, vp, vp, vp, vp, C.c_int, C.c_float, C.c_int, C.c_int, vp, vp]
     L.oro_search_by_projection_last.restype = C.c_int
+    L.oro_search_by_projection_map.argtypes = [C.c_int, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, C.c_int, C.c_float, C.c_float, vp, vp]
+    L.oro_search_by_projection_map.restype = C.c_int
     L.oro_undistort_points.argtypes = [vp, C.c_int, C.c_float, C.c_float, C.c_float, C.c_float, vp]
     L.oro_undistort_points.restype = None
     L.oro_image_bounds.argtypes = [C.c_int, C.c_int, C.c_float, C.c_float, C.c_float, C.c_float, vp, vp]
@@ -285,6 +287,21 @@ def search_by_projection_last(has_point, xw, mp_desc, mp_obs, kps_last, Tcw, Tlw
     n = lib().oro_search_by_projection_last(len(kps_last), _p(has_point), _p(xw), _p(mp_desc), _p(mp_obs), _p(kps_last), _p(Tcw), _p(Tlw),
                                             fx, fy, cx, cy, mb, mbf, _p(b), _p(sf), C.byref(grid_cur.g), _p(grid_cur.kps), _p(desc_cur),
                                             _p(ur) if ur is not None else None, len(grid_cur.kps), th, int(mono), int(check_ori), _p(cur_obs), _p(cm))
+    return cm, n
+
+
+def search_by_projection_map(in_view, proj_x, proj_y, pred_level, view_cos, mp_desc, mp_obs, scale_factors, grid_cur, desc_cur, cur_obs,
+                             th, nnratio, proj_xr=None, u_right=None):
+    """ORBmatcher::SearchByProjection(F, vpMapPoints, th) on the oracle -> (cur_match, nmatches); cur_obs in/out"""
+    f32 = lambda a: None if a is None else np.ascontiguousarray(a, np.float32)
+    in_view = np.ascontiguousarray(in_view, np.uint8); px, py, pxr, vc = f32(proj_x), f32(proj_y), f32(proj_xr), f32(view_cos)
+    lv = np.ascontiguousarray(pred_level, np.int32); mp_desc = np.ascontiguousarray(mp_desc, np.uint8)
+    mp_obs = np.ascontiguousarray(mp_obs, np.int32); sf = f32(scale_factors); ur = f32(u_right)
+    desc_cur = np.ascontiguousarray(desc_cur, np.uint8)
+    cm = np.full(len(grid_cur.kps), -1, np.int32)
+    pp = lambda a: _p(a) if a is not None else None
+    n = lib().oro_search_by_projection_map(len(in_view), _p(in_view), _p(px), _p(py), pp(pxr), _p(lv), _p(vc), _p(mp_desc), _p(mp_obs), _p(sf),
+                                           C.byref(grid_cur.g), _p(grid_cur.kps), _p(desc_cur), pp(ur), len(grid_cur.kps), th, nnratio, _p(cur_obs), _p(cm))
     return cm, n
 
 

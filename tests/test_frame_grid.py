@@ -175,3 +175,38 @@ def test_search_by_projection_last_equals_oracle(orbx, synth, mono, th, with_rig
         good = cm >= 0
         assert np.median(np.abs(k1["x"][good] - (k0["x"][cm[good]] - np.array(shifts)[layer[np.clip(np.rint(k0["y"][cm[good]]).astype(int), 0, H - 1),
                                                                                                 np.clip(np.rint(k0["x"][cm[good]]).astype(int), 0, W - 1)]]))) < 1.5
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("th,ratio,with_right", [(1.0, 0.8, False), (3.0, 0.8, False), (5.0, 0.6, True), (1.0, 1.0, True)])
+def test_search_by_projection_map_equals_oracle(orbx, synth, th, ratio, with_right):
+    """ORBmatcher::SearchByProjection(F, vpMapPoints, th) (src/ORBmatcher.cc:45-125) as Tracking::SearchLocalPoints calls it
+    (Tracking.cc:1191-1199: ORBmatcher(0.8), th 1, 3 or 5): the local map = the previous frame's keypoints predicted at their
+    shifted positions and octaves (+-1 for some), viewing cosines on both sides of 0.998."""
+    W, H = 1241, 376
+    f0, f1 = synth.frame_pair(21, W, H, shift=(6, 2))
+    ex = orbx.ORBextractor(2000, max_width=W, max_height=H)
+    k0, d0 = ex(f0); k1, d1 = ex(f1)
+    sf = ex.GetScaleFactors()
+    rng = np.random.default_rng(int(th * 10) + int(with_right))
+    n = len(k0)
+    in_view = (rng.random(n) < 0.8).astype(np.uint8)
+    px = (k0["x"] - 6 + rng.normal(0, 0.7, n)).astype(np.float32); py = (k0["y"] - 2 + rng.normal(0, 0.7, n)).astype(np.float32)
+    lv = np.clip(k0["octave"] + rng.integers(0, 2, n), 0, 7).astype(np.int32)       # GetFeaturesInArea(level - 1, level)
+    vc = np.where(rng.random(n) < 0.5, 0.9985, 0.99).astype(np.float32)
+    obs = rng.integers(1, 5, n).astype(np.int32)
+    ur = pxr = None
+    if with_right:
+        ur = (k1["x"] - rng.uniform(2, 30, len(k1))).astype(np.float32); ur[::4] = -1.0
+        pxr = (px - rng.uniform(2, 30, n)).astype(np.float32)
+    m = orbx.ORBmatcher(ratio, True, max_queries=4096, max_train=4096, max_pairs=1 << 21)
+    m.grid_build(k1, 0.0, float(W), 0.0, float(H))
+    og = O.FrameGrid(k1, 0.0, float(W), 0.0, float(H))
+    cur0 = np.full(len(k1), -1, np.int32); cur0[::9] = rng.integers(0, 3, len(cur0[::9]))
+    ca, cb = cur0.copy(), cur0.copy()
+    cm, nm = m.SearchByProjectionMap(in_view, px, py, lv, vc, d0, obs, sf, k1, d1, ca, th, pxr, ur)
+    ocm, onm = O.search_by_projection_map(in_view, px, py, lv, vc, d0, obs, sf, og, d1, cb, th, ratio, pxr, ur)
+    assert nm == onm and np.array_equal(cm, ocm) and np.array_equal(ca, cb)
+    assert nm == int((cm >= 0).sum()) or nm >= int((cm >= 0).sum())        # nmatches counts assignments (overwrites included)
+    if not with_right and th >= 3.0:
+        assert nm > 300
