@@ -473,7 +473,12 @@ static int area_pairs(orbm_matcher *m, const float *x, const float *y, const flo
     hipLaunchKernelGGL(k_area_list<0>, grid, dim3(M_THREADS), 0, s, m->grid, sx, sy, sr, smn, smx, nq, d_cnt, (const int32_t *)nullptr, (int32_t *)nullptr);
     MHIPCHK(hipGetLastError());
     const int32_t *cnt = (const int32_t *)orbm_d2h_tmp(m, d_cnt, nb4, s);
-    if (!cnt) return mfail(ORBX_E_HIP, "staging arena exhausted");
+    std::vector<int32_t> cnt_plain;
+    if (!cnt) {           // no room left in the arena this call (it grows for the next one): a plain copy
+        cnt_plain.resize((size_t)nq);
+        MHIPCHK(hipMemcpyAsync(cnt_plain.data(), d_cnt, nb4, hipMemcpyDeviceToHost, s));
+        cnt = cnt_plain.data();
+    }
     { int rc_ = orbm_sync(m, s); if (rc_ != ORBX_OK) return rc_; }
     for (int i = 0; i < nq; i++) off[i + 1] = off[i] + cnt[i];
     const int total = off[nq];
