@@ -65,5 +65,15 @@ while time.time() - t0 < budget:
     b, nb = O.search_by_projection_map(inv, px, py, lv, vc, d0, obs, sf, og, d1, cb, thm, ratio, pxr, ur)
     assert na == nb and np.array_equal(a, b) and np.array_equal(ca, cb), ("map", W, H, nf, shift, thm, ratio)
     n_ok[2] += 1
-print("stress_proj: %d / %d / %d random cases (SearchForInitialization / SearchByProjection last frame / local map) identical to the oracle in %.0f s"
-      % (n_ok[0], n_ok[1], n_ok[2], time.time() - t0))
+    # 4. the fused window search (orbm_search_area_best2): random windows, octave ranges and skip masks
+    nq = int(rng.integers(1, len(k0) + 1))
+    qx = rng.uniform(-20, W + 20, nq).astype(np.float32); qy = rng.uniform(-20, H + 20, nq).astype(np.float32)
+    qr = rng.uniform(1, 80, nq).astype(np.float32)
+    qmn = rng.integers(-1, 4, nq).astype(np.int32); qmx = np.where(rng.random(nq) < 0.3, -1, qmn + rng.integers(0, 4, nq)).astype(np.int32)
+    skip = (rng.random(len(k1)) < 0.2).astype(np.uint8) if rng.integers(0, 2) else None
+    a = m.search_area_best2(d0[:nq], qx, qy, qr, qmn, qmx, d1, skip)
+    b = og.search_area_best2(d0[:nq], qx, qy, qr, qmn, qmx, d1, skip)
+    assert all(np.array_equal(u, v) for u, v in zip(a, b)), ("area", W, H, nf, nq)
+    n_ok.append(1) if len(n_ok) == 3 else n_ok.__setitem__(3, n_ok[3] + 1)
+print("stress_proj: %d / %d / %d / %d random cases (SearchForInitialization / SearchByProjection last frame / local map / fused window search) "
+      "identical to the oracle in %.0f s" % (n_ok[0], n_ok[1], n_ok[2], n_ok[3] if len(n_ok) > 3 else 0, time.time() - t0))
