@@ -3,7 +3,8 @@
 // walk the MapPoint/KeyFrame object graph on the host; what they all share is the inner loop
 // "best / second-best DescriptorDistance over a candidate list" (SURVEY.md A10).  A maintainer keeps
 // those methods and replaces their inner loops with BestTwo()/Distances() below; INTEGRATION.md shows
-// the edit for SearchByBoW (src/ORBmatcher.cc:201-232) and SearchByProjection (:1397-1430).
+// the edit for SearchByBoW (src/ORBmatcher.cc:201-232) and SearchByProjection (:1397-1430).  The four matchers of the per-frame
+// tracking path (SearchForInitialization, SearchByBoW, SearchByProjection x 2) are here whole, over arrays.
 #pragma once
 #include <cstdint>
 #include <string>
@@ -61,6 +62,94 @@ public:
         return orbm_rot_filter(angleQ.data(), angleT.data(), match12.data(), (int)match12.size());
     }
 
+    // ---- whole matchers (include/orbm.h has the argument conventions; Frame / KeyFrame / MapPoint fields arrive as arrays) ----
+    // The Frame grid of the frame that is searched (F2 / CurrentFrame / F): Frame::AssignFeaturesToGrid
+    bool BuildGrid(const std::vector<cv::KeyPoint> &keysUn, float minX, float maxX, float minY, float maxY)
+    {
+        return ok(m_ ? orbm_grid_build(m_, (const orbx_keypoint *)keysUn.data(), (int)keysUn.size(), minX, maxX, minY, maxY) : ORBX_E_INVALID);
+    }
+    // int SearchForInitialization(Frame &F1, Frame &F2, vector<cv::Point2f> &vbPrevMatched, vector<int> &vnMatches12, int windowSize)
+    int SearchForInitialization(const std::vector<cv::KeyPoint> &keysUn1, const cv::Mat &desc1, const std::vector<cv::KeyPoint> &keysUn2,
+                                const cv::Mat &desc2, std::vector<cv::Point2f> &vbPrevMatched, std::vector<int> &vnMatches12, int windowSize = 10)
+    {
+        vnMatches12.assign(keysUn1.size(), -1);
+        int n = 0;
+        if (!m_ || !ok(orbm_search_for_initialization(m_, (const orbx_keypoint *)keysUn1.data(), desc1.data, (int)keysUn1.size(),
+                                                      (const orbx_keypoint *)keysUn2.data(), desc2.data, (int)keysUn2.size(),
+                                                      (float *)vbPrevMatched.data(), windowSize, mfNNratio, mbCheckOrientation,
+                                                      vnMatches12.data(), &n)))
+            return 0;
+        return n;
+    }
+    // int SearchByBoW(KeyFrame *pKF, Frame &F, vector<MapPoint*> &vpMapPointMatches): matchF[i] = key-frame feature or -1
+    int SearchByBoW(const std::vector<cv::KeyPoint> &keysUnKF, const cv::Mat &descKF, const std::vector<uint8_t> &validKF,
+                    const std::vector<int32_t> &kfNode, const std::vector<int32_t> &kfOff, const std::vector<int32_t> &kfIdx,
+                    const std::vector<cv::KeyPoint> &keysF, const cv::Mat &descF, const std::vector<int32_t> &fNode,
+                    const std::vector<int32_t> &fOff, const std::vector<int32_t> &fIdx, std::vector<int32_t> &matchF)
+    {
+        matchF.assign(keysF.size(), -1);
+        int n = 0;
+        if (!m_ || !ok(orbm_search_by_bow(m_, descKF.data, (const orbx_keypoint *)keysUnKF.data(), (int)keysUnKF.size(),
+                                          validKF.empty() ? nullptr : validKF.data(), kfNode.data(), kfOff.data(), kfIdx.data(), (int)kfNode.size(),
+                                          descF.data, (const orbx_keypoint *)keysF.data(), (int)keysF.size(), fNode.data(), fOff.data(), fIdx.data(),
+                                          (int)fNode.size(), mfNNratio, mbCheckOrientation, matchF.data(), &n)))
+            return 0;
+        return n;
+    }
+    // int SearchByProjection(Frame &CurrentFrame, const Frame &LastFrame, const float th, const bool bMono)
+    struct LastFrameView {          // per feature of LastFrame
+        std::vector<uint8_t> hasPoint;      // pMP && !mvbOutlier[i]
+        std::vector<float> worldPos;        // 3 per feature
+        std::vector<uint8_t> descriptors;   // pMP->GetDescriptor(), 32 per feature
+        std::vector<int32_t> observations;  // pMP->Observations()
+        const std::vector<cv::KeyPoint> *keys = nullptr;   // octave of mvKeys, angle of mvKeysUn
+        float Tcw[16];
+    };
+    struct FrameView {              // the frame that is searched; its grid must be current (BuildGrid)
+        float Tcw[16], fx, fy, cx, cy, mb, mbf, bounds[4];
+        const std::vector<float> *scaleFactors = nullptr;
+        const std::vector<cv::KeyPoint> *keysUn = nullptr;
+        const cv::Mat *descriptors = nullptr;
+        const std::vector<float> *uRight = nullptr;      // mvuRight or NULL
+        std::vector<int32_t> pointObservations;          // -1 = NULL mvpMapPoints entry, else Observations(); updated
+        std::vector<int32_t> assigned;                   // out: index of the feature / MapPoint put into mvpMapPoints[i2], or -1
+    };
+    int SearchByProjection(FrameView &Cur, const LastFrameView &Last, float th, bool bMono)
+    {
+        const int nc = (int)Cur.keysUn->size();
+        Cur.assigned.assign(nc, -1);
+        int n = 0;
+        if (!m_ || !ok(orbm_search_by_projection_last(m_, (int)Last.keys->size(), Last.hasPoint.data(), Last.worldPos.data(), Last.descriptors.data(),
+                                                      Last.observations.data(), (const orbx_keypoint *)Last.keys->data(), Cur.Tcw, Last.Tcw,
+                                                      Cur.fx, Cur.fy, Cur.cx, Cur.cy, Cur.mb, Cur.mbf, Cur.bounds, Cur.scaleFactors->data(),
+                                                      (int)Cur.scaleFactors->size(), (const orbx_keypoint *)Cur.keysUn->data(), Cur.descriptors->data,
+                                                      Cur.uRight ? Cur.uRight->data() : nullptr, nc, th, bMono, mbCheckOrientation,
+                                                      Cur.pointObservations.data(), Cur.assigned.data(), &n)))
+            return 0;
+        return n;
+    }
+    // int SearchByProjection(Frame &F, const vector<MapPoint*> &vpMapPoints, const float th)
+    struct MapPointsView {          // per MapPoint of the local map
+        std::vector<uint8_t> inView;                     // mbTrackInView && !isBad()
+        std::vector<float> projX, projY, projXR, viewCos;
+        std::vector<int32_t> predictedLevel, observations;
+        std::vector<uint8_t> descriptors;
+    };
+    int SearchByProjection(FrameView &F, const MapPointsView &P, float th = 3)
+    {
+        const int nc = (int)F.keysUn->size();
+        F.assigned.assign(nc, -1);
+        int n = 0;
+        if (!m_ || !ok(orbm_search_by_projection_map(m_, (int)P.inView.size(), P.inView.data(), P.projX.data(), P.projY.data(),
+                                                     P.projXR.empty() ? nullptr : P.projXR.data(), P.predictedLevel.data(), P.viewCos.data(),
+                                                     P.descriptors.data(), P.observations.data(), F.scaleFactors->data(), (int)F.scaleFactors->size(),
+                                                     (const orbx_keypoint *)F.keysUn->data(), F.descriptors->data,
+                                                     (F.uRight && !P.projXR.empty()) ? F.uRight->data() : nullptr, nc, th, mfNNratio,
+                                                     F.pointObservations.data(), F.assigned.data(), &n)))
+            return 0;
+        return n;
+    }
+
     static const int TH_LOW = ORBM_TH_LOW;
     static const int TH_HIGH = ORBM_TH_HIGH;
     static const int HISTO_LENGTH = ORBM_HISTO_LENGTH;
@@ -68,6 +157,7 @@ public:
     const std::string &LastError() const { return err_; }
 
 protected:
+    bool ok(int rc) { if (rc != ORBX_OK) err_ = orbm_last_error(); return rc == ORBX_OK; }
     float mfNNratio;
     bool mbCheckOrientation;
     orbm_matcher *m_ = nullptr;

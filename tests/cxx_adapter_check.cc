@@ -64,7 +64,15 @@ int main(int argc, char **argv)
     int self = 0;
     for (size_t i = 0; i < bi.size(); i++) self += (bd[i] == 0);
     extractor.FetchImagePyramid();
-    printf("%zu %016llx %d %d %d\n", keys.size(), h, self, extractor.mvImagePyramid[7].cols,
-           ORB_SLAM2::ORBmatcher::DescriptorDistance(descriptors.row(0), descriptors.row(1)));
+    // Tracking::MonocularInitialization's matcher on the frame against itself: every level-0 keypoint finds itself
+    matcher.BuildGrid(keys, 0.f, (float)W, 0.f, (float)H);
+    std::vector<cv::Point2f> prevMatched(keys.size());
+    for (size_t i = 0; i < keys.size(); i++) prevMatched[i] = keys[i].pt;
+    std::vector<int> matches12;
+    const int nInit = matcher.SearchForInitialization(keys, descriptors, keys, descriptors, prevMatched, matches12, 100);
+    int selfInit = 0, level0 = 0;
+    for (size_t i = 0; i < keys.size(); i++) { level0 += keys[i].octave == 0; selfInit += matches12[i] == (int)i; }
+    printf("%zu %016llx %d %d %d %d %d %d\n", keys.size(), h, self, extractor.mvImagePyramid[7].cols,
+           ORB_SLAM2::ORBmatcher::DescriptorDistance(descriptors.row(0), descriptors.row(1)), nInit, selfInit, level0);
     return 0;
 }

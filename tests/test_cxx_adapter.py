@@ -49,3 +49,5 @@ def test_adapter_equals_cabi(orbx, synth, tmp_path):
     assert int(out[2]) == len(kps)            # every descriptor matches itself at distance 0
     assert int(out[3]) == 179
     assert int(out[4]) == orbx.ORBmatcher.DescriptorDistance(desc[0], desc[1])
+    n_init, self_init, level0 = int(out[5]), int(out[6]), int(out[7])
+    assert level0 == int((kps["octave"] == 0).sum()) and n_init == self_init and 0.9 * level0 <= n_init <= level0
