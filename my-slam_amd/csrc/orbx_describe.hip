@@ -123,7 +123,7 @@ __device__ __forceinline__ float fast_atan2_deg(float y, float x)
 
 // cos/sin of an fp32 angle in [0, 2pi], rounded to fp32 from a double-precision evaluation
 // (Cody-Waite reduction by pi/2 with a 33-bit head, Taylor kernels to r^19 / r^20 on |r| <= pi/4).
-// Canonical semantics = correctly rounded cosf/sinf; tools/verify_sincos.py checks this
+// Canonical semantics = correctly rounded cosf/sinf; tests/tools/verify_sincos.py checks this
 // routine against the x87 long-double libm over every fp32 input of the domain.
 __device__ __forceinline__ void sincos_cr(float theta, float *cs, float *sn)
 {
@@ -164,7 +164,7 @@ __device__ __forceinline__ void sincos_cr(float theta, float *cs, float *sn)
     *sn = (float)sv;
 }
 
-// exported for the exhaustive sincos check (tools/verify_sincos.py)
+// exported for the exhaustive sincos check (tests/tools/verify_sincos.py)
 __global__ void k_sincos_probe(const float *theta, float *cs, float *sn, int n)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;

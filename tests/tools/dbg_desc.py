@@ -1,5 +1,5 @@
-import sys, numpy as np
-sys.path.insert(0,'tests')
+import os, sys, numpy as np
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import conftest, oracle_lib as O
 import my_slam_amd as M, my_slam_amd.synth as synth
 img=synth.texture(1,640,480)

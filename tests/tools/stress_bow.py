@@ -3,7 +3,7 @@
 counts, ratios, MapPoint masks and image pairs; match table and return value must be identical.  usage: stress_bow.py [seconds] [seed]"""
 import os, sys, tempfile, time
 import numpy as np
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 import torch  # noqa
 import conftest  # noqa

@@ -3,7 +3,7 @@
 seeds; every keypoint field and descriptor byte must agree.  usage: stress_parity.py [seconds] [seed]"""
 import os, sys, time
 import numpy as np
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 import torch
 import conftest  # noqa

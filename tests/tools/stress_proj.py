@@ -3,7 +3,7 @@
 SearchByProjection(CurrentFrame, LastFrame) and SearchByProjection(F, vpMapPoints).  usage: stress_proj.py [seconds] [seed]"""
 import os, sys, time
 import numpy as np
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 import torch  # noqa
 import conftest  # noqa

@@ -3,7 +3,7 @@
 canonical definition "correctly rounded fp32 cos/sin of the fp32 angle" (DESIGN.md §2), evaluated on
 the host with the x87 80-bit cosl/sinl of the oracle library, over EVERY fp32 value in [0, 2*pi]
 (the domain of kpt.angle * factorPI, src/ORBextractor.cc:114).  Run on the GPU box:
-    python tools/verify_sincos.py [--stride N] [--out profiles/sincos_exhaustive.json]
+    python tests/tools/verify_sincos.py [--stride N] [--out profiles/sincos_exhaustive.json]
 """
 import argparse
 import ctypes as C
@@ -15,7 +15,7 @@ from concurrent.futures import ThreadPoolExecutor
 
 import numpy as np
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 import conftest  # noqa: F401,E402
 import oracle_lib as O  # noqa: E402
