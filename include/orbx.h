@@ -78,6 +78,15 @@ int orbx_get_features_per_level(const orbx_extractor *h, int *quota);
 int orbx_capacity(const orbx_extractor *h);
 
 /*
+ * The same call in two halves, for callers that have host work to do while the GPU extracts (e.g. the pose solvers of
+ * frame k while frame k+1 is in flight on a second handle): orbx_extract_begin stages the image and enqueues copies and
+ * kernels on the handle's stream without waiting; orbx_extract_end waits and fills the outputs.  One call may be in flight
+ * per handle; `image` may be released as soon as begin returns.  begin on an empty image followed by end gives *n = 0.
+ */
+int orbx_extract_begin(orbx_extractor *h, const uint8_t *image, int width, int height, int stride);
+int orbx_extract_end(orbx_extractor *h, orbx_keypoint *keypoints, uint8_t *descriptors, int cap, int *n);
+
+/*
  * ORBextractor::operator() (include/ORBextractor.h:59).  Host image (CV_8UC1, `stride` bytes per
  * row), host outputs with room for `cap` >= orbx_capacity() entries; *n receives the count.
  * An empty image (NULL / w<=0 / h<=0) is the reference's silent return: ORBX_OK with *n = 0.

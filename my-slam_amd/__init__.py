@@ -70,6 +70,10 @@ def lib():
     L.orbx_get_features_per_level.argtypes = [vp, vp]
     L.orbx_capacity.argtypes = [vp]
     L.orbx_extract.argtypes = [vp, vp, C.c_int, C.c_int, C.c_int, vp, vp, C.c_int, ip]
+    L.orbx_extract_begin.argtypes = [vp, vp, C.c_int, C.c_int, C.c_int]
+    L.orbx_extract_begin.restype = C.c_int
+    L.orbx_extract_end.argtypes = [vp, vp, vp, C.c_int, ip]
+    L.orbx_extract_end.restype = C.c_int
     L.orbx_extract_batch.argtypes = [vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_size_t, vp, vp, C.c_int, vp]
     L.orbx_extract_batch_device.argtypes = [vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_size_t, vp, vp, C.c_int, vp, vp, vp]
     L.orbx_level_size.argtypes = [vp, C.c_int, ip, ip]
@@ -272,6 +276,22 @@ class ORBextractor:
         desc = np.zeros((self.cap, 32), np.uint8)
         n = C.c_int()
         _chk(self.L.orbx_extract(self.h, _p(image), W, H, image.strides[0], _p(kps), _p(desc), self.cap, C.byref(n)))
+        return kps[:n.value].copy(), desc[:n.value].copy()
+
+    def extract_begin(self, image):
+        """First half of __call__: stage + enqueue, no wait (include/orbx.h: orbx_extract_begin)."""
+        if image is None or image.size == 0:
+            _chk(self.L.orbx_extract_begin(self.h, None, 0, 0, 0))
+            return
+        assert image.dtype == np.uint8 and image.ndim == 2 and image.strides[1] == 1
+        _chk(self.L.orbx_extract_begin(self.h, image.ctypes.data_as(C.c_void_p), image.shape[1], image.shape[0], image.strides[0]))
+
+    def extract_end(self):
+        """Second half: wait and return (keypoints, descriptors)."""
+        kps = np.zeros(self.cap, KP_DTYPE)
+        desc = np.zeros((self.cap, 32), np.uint8)
+        n = C.c_int(0)
+        _chk(self.L.orbx_extract_end(self.h, _p(kps), _p(desc), self.cap, C.byref(n)))
         return kps[:n.value].copy(), desc[:n.value].copy()
 
     def extract_batch(self, images):

@@ -64,6 +64,7 @@ struct orbx_extractor {
     uint8_t *h_in = nullptr;
     orbx_keypoint *h_kps = nullptr; uint8_t *h_desc = nullptr; int32_t *h_counts = nullptr, *h_status = nullptr;
     uint8_t *d_out = nullptr, *h_out = nullptr; size_t out_hdr = 0, out_kps_bytes = 0, out_bytes = 0;   // the block the eight pointers above point into
+    int inflight = 0, inflight_frames = 0;      // orbx_extract_begin / orbx_extract_end
     int profiling = 0; hipEvent_t ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr}; float stage_ms[4] = {0, 0, 0, 0};
     // profiling == 2: the stage events of the last ORBX_PROF_RING calls are recorded and never waited for by the library
     hipEvent_t evr[ORBX_PROF_RING][5] = {}; long long ring_calls = 0;
@@ -525,6 +526,7 @@ extern "C" int orbx_extract_batch(orbx_extractor *h, const uint8_t *images, int 
     if (!h) return fail(ORBX_E_INVALID, "NULL handle");
     if (!counts) return fail(ORBX_E_INVALID, "counts is NULL");
     for (int k = 0; k < std::max(nframes, 0); k++) counts[k] = 0;
+    if (h->inflight) return fail(ORBX_E_INVALID, "an orbx_extract_begin call is in flight on this handle");
     if (!images || width <= 0 || height <= 0 || nframes <= 0) return ORBX_OK;   // :1048 empty image: silent return
     if (!keypoints || !descriptors) return fail(ORBX_E_INVALID, "NULL output buffer");
     if (nframes > h->max_batch) return fail(ORBX_E_INVALID, "nframes=%d (max_batch=%d)", nframes, h->max_batch);
@@ -567,6 +569,57 @@ extern "C" int orbx_extract_batch(orbx_extractor *h, const uint8_t *images, int 
         memcpy(descriptors + (size_t)k * cap * 32, h->h_desc + (size_t)k * ocap * 32, (size_t)32 * n);
         counts[k] = n;
     }
+    return ORBX_OK;
+}
+
+extern "C" int orbx_extract_begin(orbx_extractor *h, const uint8_t *image, int width, int height, int stride)
+{
+    if (!h) return fail(ORBX_E_INVALID, "NULL handle");
+    if (h->inflight) return fail(ORBX_E_INVALID, "orbx_extract_begin: a call is already in flight on this handle");
+    h->inflight_frames = 0;
+    if (!image || width <= 0 || height <= 0) { h->inflight = 1; return ORBX_OK; }     // :1048 empty image
+    if (stride < width) return fail(ORBX_E_INVALID, "row_stride %d < width %d", stride, width);
+    if (width > h->max_w || height > h->max_h) return fail(ORBX_E_SHAPE, "frame %dx%d exceeds the handle's max %dx%d", width, height, h->max_w, h->max_h);
+    HIPCHK(hipSetDevice(h->device));
+    hipStream_t s = h->stream;
+    if (stride == h->in_stride) memcpy(h->h_in, image, (size_t)stride * height);
+    else for (int y = 0; y < height; y++) memcpy(h->h_in + (size_t)y * h->in_stride, image + (size_t)y * stride, (size_t)width);
+    HIPCHK(hipMemcpyAsync(h->d_input, h->h_in, (size_t)h->in_stride * height, hipMemcpyHostToDevice, s));
+    int rc = enqueue(h, h->d_input, 1, width, height, h->in_stride, (long long)h->in_frame, h->d_kps, h->d_desc, h->d_counts, h->d_status, s);
+    if (rc != ORBX_OK) return rc;
+    const int ocap = h->max_plan.out_cap;
+    if (h->max_batch == 1) {
+        HIPCHK(hipMemcpyAsync(h->h_out, h->d_out, h->out_bytes, hipMemcpyDeviceToHost, s));
+    } else {
+        HIPCHK(hipMemcpyAsync(h->h_out, h->d_out, h->out_hdr, hipMemcpyDeviceToHost, s));
+        HIPCHK(hipMemcpyAsync(h->h_kps, h->d_kps, sizeof(orbx_keypoint) * (size_t)ocap, hipMemcpyDeviceToHost, s));
+        HIPCHK(hipMemcpyAsync(h->h_desc, h->d_desc, (size_t)32 * ocap, hipMemcpyDeviceToHost, s));
+    }
+    h->inflight = 1; h->inflight_frames = 1;
+    return ORBX_OK;
+}
+
+extern "C" int orbx_extract_end(orbx_extractor *h, orbx_keypoint *keypoints, uint8_t *descriptors, int cap, int *n)
+{
+    if (!h || !n) return fail(ORBX_E_INVALID, "NULL argument");
+    *n = 0;
+    if (!h->inflight) return fail(ORBX_E_INVALID, "orbx_extract_end without orbx_extract_begin");
+    h->inflight = 0;
+    if (h->inflight_frames == 0) return ORBX_OK;
+    if (!keypoints || !descriptors) return fail(ORBX_E_INVALID, "NULL output buffer");
+    HIPCHK(hipSetDevice(h->device));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    int rc = finish_profile(h);
+    if (rc != ORBX_OK) return rc;
+    if (h->h_status[0] != ORBX_OK)
+        return fail(h->h_status[0], "device status %d (%s)", h->h_status[0],
+                    h->h_status[0] == ORBX_E_CAND_OVERFLOW ? "FAST candidate buffer overflow" :
+                    h->h_status[0] == ORBX_E_TREE_OVERFLOW ? "quadtree arena overflow" : "capacity");
+    const int cnt = h->h_counts[0];
+    if (cnt > cap) return fail(ORBX_E_CAPACITY, "%d keypoints, caller capacity %d (use orbx_capacity())", cnt, cap);
+    memcpy(keypoints, h->h_kps, sizeof(orbx_keypoint) * cnt);
+    memcpy(descriptors, h->h_desc, (size_t)32 * cnt);
+    *n = cnt;
     return ORBX_OK;
 }
 

@@ -233,3 +233,31 @@ def test_ring_profiling_mode(orbx, synth):
     ex.set_profiling(0)
     ref = ex(synth.stream(3, W, H, B)[0])
     assert int(c[0]) == len(ref[0])
+
+
+def test_extract_begin_end_pipelined(orbx, synth):
+    """orbx_extract_begin / orbx_extract_end: two handles with a frame in flight on each give what the blocking call gives;
+    misuse (second begin, end without begin, blocking call while in flight) is an error."""
+    W, H = 640, 480
+    frames = synth.stream(9, W, H, 6)
+    ref = orbx.ORBextractor(1000, max_width=W, max_height=H)
+    want = [ref(frames[k]) for k in range(6)]
+    ex = [orbx.ORBextractor(1000, max_width=W, max_height=H), orbx.ORBextractor(1000, max_width=W, max_height=H)]
+    ex[0].extract_begin(frames[0])
+    for k in range(6):
+        if k + 1 < 6:
+            ex[(k + 1) & 1].extract_begin(frames[k + 1])
+        kp, de = ex[k & 1].extract_end()
+        assert kp.tobytes() == want[k][0].tobytes() and np.array_equal(de, want[k][1])
+    ex[0].extract_begin(frames[0])
+    with pytest.raises(orbx.OrbxError):
+        ex[0].extract_begin(frames[1])
+    with pytest.raises(orbx.OrbxError):
+        ex[0](frames[1])
+    kp, de = ex[0].extract_end()
+    assert kp.tobytes() == want[0][0].tobytes()
+    with pytest.raises(orbx.OrbxError):
+        ex[0].extract_end()
+    ex[1].extract_begin(None)                   # the reference's silent return on an empty image
+    kp, de = ex[1].extract_end()
+    assert len(kp) == 0 and de.shape == (0, 32)

@@ -1,6 +1,6 @@
 // track_harness.cc -- BASELINE config 5's per-frame loop, host side in C++ through the C ABI exactly as INTEGRATION.md
 // wires it into the reference:
-//     Frame::ExtractORB                 -> orbx_extract
+//     Frame::ExtractORB                 -> orbx_extract_end(frame k) + orbx_extract_begin(frame k + 1) on a second handle
 //     Frame::AssignFeaturesToGrid       -> orbm_grid_build
 //     Frame::ComputeBoW                 -> orbv_transform_features + orbv_bow_vector + orbv_feature_vector
 //     Tracking::TrackReferenceKeyFrame  -> orbm_search_by_bow            (ORBmatcher(0.7, true), src/Tracking.cc:774-779)
@@ -60,9 +60,12 @@ int main(int argc, char **argv)
     if (!f || fread(frames.data(), 1, frames.size(), f) != frames.size()) { fprintf(stderr, "cannot read %s\n", fpath); return 1; }
     fclose(f);
 
-    orbx_extractor *ex = nullptr; orbm_matcher *mt = nullptr; orbv_vocabulary *voc = nullptr;
-    CHK(orbx_create(&ex, NF, 1.2f, 8, 20, 7, 0, W, H, 1));
-    const int cap = orbx_capacity(ex);
+    // two extractor handles: frame k + 1 is staged and enqueued (orbx_extract_begin) as soon as frame k has been collected,
+    // so its extraction runs on the GPU underneath the host's matching and pose work on frame k
+    orbx_extractor *exs[2] = {nullptr, nullptr}; orbm_matcher *mt = nullptr; orbv_vocabulary *voc = nullptr;
+    CHK(orbx_create(&exs[0], NF, 1.2f, 8, 20, 7, 0, W, H, 1));
+    CHK(orbx_create(&exs[1], NF, 1.2f, 8, 20, 7, 0, W, H, 1));
+    const int cap = orbx_capacity(exs[0]);
     CHK(orbm_create(&mt, 0, cap, cap, 1 << 21));
     CHK(orbv_load_text(&voc, vpath, 0));
 
@@ -87,8 +90,10 @@ int main(int argc, char **argv)
     for (int k = 0; k < K; k++) {
         cur.kps.resize(cap); cur.desc.resize((size_t)cap * 32);
         cur.fv_node.resize(cap); cur.fv_off.resize(cap + 1); cur.fv_idx.resize(cap);
+        if (k == 0) CHK(orbx_extract_begin(exs[0], frames.data(), W, H, W));
         const double t0 = now_ms();
-        CHK(orbx_extract(ex, frames.data() + (size_t)k * W * H, W, H, W, cur.kps.data(), cur.desc.data(), cap, &cur.n));
+        CHK(orbx_extract_end(exs[k & 1], cur.kps.data(), cur.desc.data(), cap, &cur.n));
+        if (k + 1 < K) CHK(orbx_extract_begin(exs[(k + 1) & 1], frames.data() + (size_t)(k + 1) * W * H, W, H, W));
         const double t1 = now_ms();
         CHK(orbm_grid_build(mt, cur.kps.data(), cur.n, 0.f, (float)W, 0.f, (float)H));
         const double t2 = now_ms();
@@ -206,6 +211,6 @@ int main(int argc, char **argv)
            "\"matches_per_frame\": {\"bow\": %.1f, \"projection\": %.1f}}\n",
            W, H, NF, (int)t_all.size(), med, med > 0 ? 1000.0 / med : 0.0, sm[0], sm[1], sm[2], sm[3], sm[4],
            (double)nm_bow / std::max(K - 1, 1), (double)nm_proj / std::max(K - 1, 1));
-    orbv_destroy(voc); orbm_destroy(mt); orbx_destroy(ex);
+    orbv_destroy(voc); orbm_destroy(mt); orbx_destroy(exs[0]); orbx_destroy(exs[1]);
     return 0;
 }
