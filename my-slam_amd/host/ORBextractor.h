@@ -57,6 +57,33 @@ public:
         int n = 0;
         const int rc = orbx_extract(h_, im.data, im.cols, im.rows, (int)im.step, kp_.data(), tmp.data, cap_, &n);
         if (rc != ORBX_OK) { err_ = orbx_last_error(); descriptors.release(); return; }
+        fill(tmp, n, keypoints, descriptors);
+    }
+
+    // operator() in two halves (orbx_extract_begin / orbx_extract_end): Begin returns as soon as the image is staged and the
+    // work is queued; End waits and fills the outputs.  One call in flight per extractor (the stereo pair has two anyway).
+    bool Begin(cv::InputArray image)
+    {
+        const cv::Mat &im = image;
+        if (!h_) return false;
+        const int rc = im.empty() ? orbx_extract_begin(h_, nullptr, 0, 0, 0) : orbx_extract_begin(h_, im.data, im.cols, im.rows, (int)im.step);
+        if (rc != ORBX_OK) err_ = orbx_last_error();
+        return rc == ORBX_OK;
+    }
+    void End(std::vector<cv::KeyPoint> &keypoints, cv::OutputArray descriptors)
+    {
+        keypoints.clear();
+        if (!h_) { descriptors.release(); return; }
+        cv::Mat tmp(cap_, 32, cv::CV_8U);
+        int n = 0;
+        const int rc = orbx_extract_end(h_, kp_.data(), tmp.data, cap_, &n);
+        if (rc != ORBX_OK) { err_ = orbx_last_error(); descriptors.release(); return; }
+        fill(tmp, n, keypoints, descriptors);
+    }
+
+private:
+    void fill(const cv::Mat &tmp, int n, std::vector<cv::KeyPoint> &keypoints, cv::OutputArray descriptors)
+    {
         if (n == 0) { descriptors.release(); return; }                   // :1066-1067
         descriptors.create(n, 32, cv::CV_8U);                            // :1070
         for (int i = 0; i < n; i++) memcpy(descriptors.ptr<uint8_t>(i), tmp.ptr<uint8_t>(i), 32);
@@ -69,6 +96,7 @@ public:
         }
     }
 
+public:
     int inline GetLevels() { return nlevels_; }
     float inline GetScaleFactor() { return scaleFactor_; }
     std::vector<float> inline GetScaleFactors() { return mvScaleFactor; }

@@ -58,6 +58,14 @@ int main(int argc, char **argv)
         const unsigned char *d = descriptors.ptr<unsigned char>((int)i);
         for (int b = 0; b < 32; b++) { h ^= d[b]; h *= 1099511628211ull; }
     }
+    {   // the two-halves form gives the same frame
+        std::vector<cv::KeyPoint> keys2;
+        cv::Mat desc2;
+        if (!extractor.Begin(im)) { fprintf(stderr, "Begin failed: %s\n", extractor.LastError().c_str()); return 3; }
+        extractor.End(keys2, desc2);
+        if (keys2.size() != keys.size() || memcmp(keys2.data(), keys.data(), keys.size() * sizeof(cv::KeyPoint)) ||
+            memcmp(desc2.data, descriptors.data, keys.size() * 32)) { fprintf(stderr, "Begin/End differs from operator()\n"); return 4; }
+    }
     ORB_SLAM2::ORBmatcher matcher(0.9f, true);
     std::vector<int32_t> bi, bd, sd;
     matcher.BestTwo(descriptors, descriptors, nullptr, nullptr, bi, bd, sd);
