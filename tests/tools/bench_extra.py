@@ -63,6 +63,24 @@ out["device_1920x1080_n4000_b1"] = dev_bench(1920, 1080, 4000, 1, 2)
 out["device_1241x376_n2000_b32"] = dev_bench(1241, 376, 2000, 32, 5)
 out["device_640x480_n1000_b1"] = dev_bench(640, 480, 1000, 1, 4)
 
+# ---- a stereo pair (Frame.cc:78-81 extracts left and right on two threads): two handles, blocking one after the other
+# vs both in flight through orbx_extract_begin / orbx_extract_end ----
+fl, fr = synth.frame_pair(7, 1241, 376, shift=(9, 0))
+el = M.ORBextractor(2000, max_width=1241, max_height=376); er = M.ORBextractor(2000, max_width=1241, max_height=376)
+for _ in range(10):
+    el(fl); er(fr)
+ts = []
+for _ in range(100):
+    t0 = time.perf_counter(); a = el(fl); b = er(fr); ts.append(time.perf_counter() - t0)
+seq = float(np.median(ts))
+ts = []
+for _ in range(100):
+    t0 = time.perf_counter(); el.extract_begin(fl); er.extract_begin(fr); a2 = el.extract_end(); b2 = er.extract_end(); ts.append(time.perf_counter() - t0)
+ovl = float(np.median(ts))
+assert a2[0].tobytes() == a[0].tobytes() and np.array_equal(b2[1], b[1])
+out["stereo_pair_1241x376_n2000"] = {"ms_blocking_left_then_right": round(seq * 1e3, 4), "ms_both_in_flight": round(ovl * 1e3, 4)}
+del el, er
+
 # ---- N1 windowed search ----
 f0, f1 = synth.frame_pair(2, 1241, 376)
 e = M.ORBextractor(2000, max_width=1241, max_height=376)
