@@ -82,6 +82,7 @@ int orbx_capacity(const orbx_extractor *h);
  * frame k while frame k+1 is in flight on a second handle): orbx_extract_begin stages the image and enqueues copies and
  * kernels on the handle's stream without waiting; orbx_extract_end waits and fills the outputs.  One call may be in flight
  * per handle; `image` may be released as soon as begin returns.  begin on an empty image followed by end gives *n = 0.
+ * From the second call of a shape on, begin replays one HIP graph (upload, kernels, download) instead of a dozen launches.
  */
 int orbx_extract_begin(orbx_extractor *h, const uint8_t *image, int width, int height, int stride);
 int orbx_extract_end(orbx_extractor *h, orbx_keypoint *keypoints, uint8_t *descriptors, int cap, int *n);
