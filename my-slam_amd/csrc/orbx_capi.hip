@@ -665,6 +665,13 @@ extern "C" int orbx_extract(orbx_extractor *h, const uint8_t *image, int width, 
                             orbx_keypoint *keypoints, uint8_t *descriptors, int cap, int *n)
 {
     if (!n) return fail(ORBX_E_INVALID, "n is NULL");
+    if (h && h->max_batch == 1 && h->profiling == 0 && !h->inflight) {      // the two halves back to back: one HIP graph per shape
+        *n = 0;
+        int rc = orbx_extract_begin(h, image, width, height, stride);
+        if (rc != ORBX_OK) return rc;
+        if (!keypoints || !descriptors) { h->inflight = 0; if (h->inflight_frames) (void)hipStreamSynchronize(h->stream); return fail(ORBX_E_INVALID, "NULL output buffer"); }
+        return orbx_extract_end(h, keypoints, descriptors, cap, n);
+    }
     return orbx_extract_batch(h, image, 1, width, height, stride, (size_t)stride * (size_t)std::max(height, 0),
                               keypoints, descriptors, cap, n);
 }
