@@ -241,7 +241,11 @@ def test_extract_begin_end_pipelined(orbx, synth):
     W, H = 640, 480
     frames = synth.stream(9, W, H, 6)
     ref = orbx.ORBextractor(1000, max_width=W, max_height=H)
-    want = [ref(frames[k]) for k in range(6)]
+    want = [ref(frames[k]) for k in range(6)]               # calls 2.. of the handle replay its HIP graph
+    oex = O.Extractor(1000)
+    for k in (0, 1, 5):
+        okps, odesc, _ = oex.extract(frames[k])
+        assert want[k][0].tobytes() == okps.tobytes() and np.array_equal(want[k][1], odesc)
     ex = [orbx.ORBextractor(1000, max_width=W, max_height=H), orbx.ORBextractor(1000, max_width=W, max_height=H)]
     ex[0].extract_begin(frames[0])
     for k in range(6):
