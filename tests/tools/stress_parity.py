@@ -46,6 +46,10 @@ while time.time() - t0 < budget:
         a, b = kps[name], okps[name]
         assert np.array_equal(a.view(np.uint32) if a.dtype.kind == "f" else a, b.view(np.uint32) if b.dtype.kind == "f" else b), "%s: %s" % (name, tag)
     assert np.array_equal(desc, odesc), "descriptors: " + tag
+    if n_ok % 3 == 0:     # the same handle again: the second and third call of a shape capture and replay the HIP graph
+        for rep in range(2):
+            k2, d2 = ex(img)
+            assert k2.tobytes() == kps.tobytes() and np.array_equal(d2, desc), "graph replay %d: %s" % (rep, tag)
     if n_ok % 7 == 0:     # the batched path (other grids, XCD-aware order over several frames) must give the same frames
         B = int(rng.integers(2, 6))
         stack = np.stack([np.ascontiguousarray(img), np.ascontiguousarray(img[::-1, ::-1]), np.ascontiguousarray(img)] + [np.ascontiguousarray(img)] * (B - 3))[:B]
