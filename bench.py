@@ -4,9 +4,15 @@
 One step = one pass of the hot path over one batch of synthetic frames that are already resident in
 HBM: 8-level pyramid -> per-cell FAST -> quadtree -> orientation + blur + rBRIEF for every frame of
 the batch, then best/second-best Hamming matching of every frame against its predecessor, all
-through the C ABI of my-slam_amd/lib/liborbx.so.  With --gpus N (launched by torch.distributed.run,
-one rank per GPU) every rank processes its own batch (weak scaling: frames are independent units,
-no data-path collective) and RCCL over xGMI only gathers the keypoint/descriptor buffers to rank 0.
+through the C ABI of my-slam_amd/lib/liborbx.so.
+
+--gpus N: one process per GPU.  Started by a launcher (torch.distributed.run sets WORLD_SIZE) the
+process is one rank; started plainly with --gpus N > 1 it starts the N ranks itself (before anything
+touches the GPU) and relays rank 0's line.  The ranks cut ONE synthetic stream into contiguous blocks
+(my-slam_amd/shard.py): --scaling weak = --batch frames per GPU (default), strong = --batch frames in
+total (BASELINE configs[3]: 64 frames over 1/2/4/8 GPUs).  No data-path collective: per step one
+boundary frame (<= 62 KB) goes to the next rank for the pair that straddles two blocks, and one
+gather brings the keypoint/descriptor/match block back to rank 0.
 
 Prints ONE JSON line on rank 0 (contract in the task prompt): value = keypoints/s over all ranks.
 """
@@ -17,9 +23,56 @@ import os
 import sys
 import time
 
-import numpy as np
-
 ROOT = os.path.dirname(os.path.abspath(__file__))
+METRIC = "ORB keypoints/s + frames/s, 1000 feats/frame @640x480, 1/2/4/8 GPU"
+
+
+def parse_args(argv=None):
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--width", type=int, default=640)
+    ap.add_argument("--height", type=int, default=480)
+    ap.add_argument("--nfeatures", type=int, default=1000)
+    ap.add_argument("--batch", type=int, default=64, help="frames per GPU per step (weak) / frames in total (strong)")
+    ap.add_argument("--scaling", choices=("weak", "strong"), default="weak")
+    ap.add_argument("--subbatches", type=int, default=0, help="0 = library default")
+    ap.add_argument("--no-match", action="store_true")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-pipelined", action="store_true", help="skip the extra two-stream / HIP-graph throughput pass")
+    ap.add_argument("--no-host-api", action="store_true", help="skip the host-buffer API (PCIe inclusive) measurement")
+    ap.add_argument("--no-extra-configs", action="store_true", help="skip the 8x1920x1080 n=4000 extract+match step (BASELINE configs[2])")
+    ap.add_argument("--pipelined-streams", type=int, default=2)
+    ap.add_argument("--cpu-budget", type=float, default=12.0)
+    return ap.parse_args(argv)
+
+
+def launch_ranks(args):
+    """--gpus N > 1 without a launcher: start N ranks with torch.distributed.run.  Nothing in this process has touched
+    the GPU (torch is not even imported), the ranks are ordinary children, rank 0's JSON line is relayed."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    p = subprocess.run(cmd, stdout=subprocess.PIPE, env=env, text=True)
+    line = None
+    for ln in p.stdout.splitlines():
+        s = ln.strip()
+        if s.startswith("{") and '"metric"' in s:
+            line = s
+        elif s:
+            print(ln, file=sys.stderr)
+    if p.returncode != 0 or line is None:
+        print("bench.py: the %d-rank run failed (exit code %d%s)" % (args.gpus, p.returncode, "" if line else ", no result line"), file=sys.stderr)
+        return p.returncode or 1
+    print(line)
+    return 0
 
 
 def load_pkg():
@@ -35,6 +88,7 @@ def load_pkg():
 
 
 def level_geometry(W, H, nlevels=8, scale=1.2):
+    import numpy as np
     sf = np.float32(1.0)
     out = []
     for l in range(nlevels):
@@ -121,39 +175,59 @@ def cpu_baseline(frames, nfeatures, budget_s=12.0, all_cores_s=8.0):
     return out
 
 
-def pipelined_pass(pkg, torch, frames, W, H, B, NF, device, do_match, steps, nk_per_step, nstreams=2):
+class DevicePath:
+    """The hot path on one GPU for `B` resident frames: extractor + matcher handles and the flat result blocks of
+    my-slam_amd/shard.py.  step() = shard.run_step with the HIP library behind both callbacks."""
+
+    def __init__(self, pkg, torch, shard, frames, W, H, B, NF, device, do_match, rank=0, world=1, nslot=1, stream=None):
+        self.pkg, self.torch, self.shard = pkg, torch, shard
+        self.frames, self.W, self.H, self.B, self.rank, self.world = frames, W, H, B, rank, world
+        self.ex = pkg.ORBextractor(NF, 1.2, 8, 20, 7, device=device, max_width=W, max_height=H, max_batch=B)
+        self.cap = self.ex.cap
+        self.layout = shard.FlatLayout(B, self.cap)
+        self.bufs = [self.layout.alloc("cuda") for _ in range(nslot)]
+        self.status = torch.zeros(B, dtype=torch.int32, device="cuda")
+        self.do_match = do_match
+        self.mt = pkg.ORBmatcher(0.9, True, device=device, max_queries=self.cap, max_train=self.cap, max_pairs=1) if do_match else None
+        self.stream = stream
+        self.nown = B
+
+    def extract_into(self, buf, s):
+        kps, desc, _, counts, _ = self.layout.views(buf)
+        fr = self.frames
+        self.ex.extract_batch_device(fr.data_ptr(), self.nown, self.W, self.H, fr.stride(1), fr.stride(0),
+                                     kps[1].data_ptr(), desc[1].data_ptr(), counts[1:].data_ptr(), self.status.data_ptr(), s)
+
+    def match_slots(self, buf, first, npairs, s):
+        if not self.do_match or npairs < 1:
+            return
+        kps, desc, m12, counts, nmatch = self.layout.views(buf)
+        self.mt.match_batch_device(desc[first].data_ptr(), kps[first].data_ptr(), counts[first:].data_ptr(),
+                                   desc[first - 1].data_ptr(), kps[first - 1].data_ptr(), counts[first - 1:].data_ptr(),
+                                   self.cap, npairs, m12[first].data_ptr(), nmatch[first:].data_ptr(), stream=s)
+
+    def step(self, k=0, group=None, comm=None):
+        buf, s = self.bufs[k], self.stream.cuda_stream
+        return self.shard.run_step(self.layout, buf, self.rank, self.world, self.nown,
+                                   lambda *_: self.extract_into(buf, s), lambda first, npairs: self.match_slots(buf, first, npairs, s),
+                                   group=group, **(comm or {}))
+
+
+def pipelined_pass(pkg, torch, shard, frames, W, H, B, NF, device, do_match, steps, nk_per_step, nstreams=2):
     """Throughput of the same steps issued round-robin on `nstreams` streams, each with its own handles and buffers and one
     captured HIP graph per step (13 kernels, one host call)."""
-    class Pipe:
-        pass
     pipes = []
     for _ in range(nstreams):
-        p = Pipe()
-        p.ex = pkg.ORBextractor(NF, 1.2, 8, 20, 7, device=device, max_width=W, max_height=H, max_batch=B)
-        cap = p.ex.cap
-        p.kps = torch.zeros((B, cap, 7), device="cuda"); p.desc = torch.zeros((B, cap, 32), dtype=torch.uint8, device="cuda")
-        p.cnt = torch.zeros(B, dtype=torch.int32, device="cuda"); p.status = torch.zeros(B, dtype=torch.int32, device="cuda")
-        p.mt = pkg.ORBmatcher(0.9, True, device=device, max_queries=cap, max_train=cap, max_pairs=1) if do_match else None
-        p.m12 = torch.full((B, cap), -1, dtype=torch.int32, device="cuda"); p.nm = torch.zeros(B, dtype=torch.int32, device="cuda")
-        p.stream = torch.cuda.Stream()
+        p = DevicePath(pkg, torch, shard, frames, W, H, B, NF, device, do_match, stream=torch.cuda.Stream())
         pipes.append(p)
-
-    def kernels(p):
-        sp = p.stream.cuda_stream
-        p.ex.extract_batch_device(frames.data_ptr(), B, W, H, frames.stride(1), frames.stride(0),
-                                  p.kps.data_ptr(), p.desc.data_ptr(), p.cnt.data_ptr(), p.status.data_ptr(), sp)
-        if do_match:
-            cap = p.ex.cap
-            p.mt.match_batch_device(p.desc.data_ptr() + cap * 32, p.kps.data_ptr() + cap * 28, p.cnt.data_ptr() + 4,
-                                    p.desc.data_ptr(), p.kps.data_ptr(), p.cnt.data_ptr(), cap, B - 1,
-                                    p.m12.data_ptr() + cap * 4, p.nm.data_ptr() + 4, stream=sp)
     for p in pipes:                     # size the workspaces, then capture
-        kernels(p); kernels(p)
+        with torch.cuda.stream(p.stream):
+            p.step(); p.step()
     torch.cuda.synchronize()
     for p in pipes:
         p.graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(p.graph, stream=p.stream):
-            kernels(p)
+            p.step()
     ends = [torch.cuda.Event() for _ in range(steps + 2 * nstreams)]
 
     def run(n, base):
@@ -171,41 +245,92 @@ def pipelined_pass(pkg, torch, frames, W, H, B, NF, device, do_match, steps, nk_
     torch.cuda.synchronize()
     el = (time.perf_counter() - t0) / steps
     for p in pipes:
-        if int(p.status.abs().sum().item()) != 0 or int(p.cnt.sum().item()) != nk_per_step:
+        counts = p.layout.views(p.bufs[0])[3]
+        if int(p.status.abs().sum().item()) != 0 or int(counts[1:].sum().item()) != nk_per_step:
             raise RuntimeError("pipelined pass produced different results")
     return {"streams": nstreams, "hip_graph_per_step": True, "steps": steps, "ms_per_step": round(el * 1e3, 4),
             "frames_per_s": round(B / el, 1), "keypoints_per_s": round(nk_per_step / el, 1)}
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=100)
-    ap.add_argument("--warmup", type=int, default=10)
-    ap.add_argument("--width", type=int, default=640)
-    ap.add_argument("--height", type=int, default=480)
-    ap.add_argument("--nfeatures", type=int, default=1000)
-    ap.add_argument("--batch", type=int, default=64, help="frames per GPU per step")
-    ap.add_argument("--subbatches", type=int, default=0, help="0 = library default")
-    ap.add_argument("--no-overlap", action="store_true", help="do not overlap the resize chain with FAST on level 0")
-    ap.add_argument("--no-match", action="store_true")
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-pipelined", action="store_true", help="skip the extra two-stream / HIP-graph throughput pass")
-    ap.add_argument("--pipelined-streams", type=int, default=2)
-    ap.add_argument("--cpu-budget", type=float, default=12.0)
-    args = ap.parse_args()
+def host_api_pass(pkg, frames_np, W, H, NF, device, reps=12):
+    """The reference's own call shape: host images in, host keypoints/descriptors out (orbx_extract_batch), PCIe
+    inclusive.  Reported beside the contract line, never as `value`."""
+    import numpy as np
+    B = len(frames_np)
+    ex = pkg.ORBextractor(NF, 1.2, 8, 20, 7, device=device, max_width=W, max_height=H, max_batch=B)
+    for _ in range(3):
+        ex.extract_batch_raw(frames_np)
+    ts = []
+    for _ in range(reps):
+        t0 = time.perf_counter()
+        counts = ex.extract_batch_raw(frames_np)[2]
+        ts.append(time.perf_counter() - t0)
+    med = float(np.median(ts))
+    return {"entry": "orbx_extract_batch (host buffers in and out, blocking)", "frames": B, "ms_per_batch": round(med * 1e3, 4),
+            "ms_per_64_frames": round(med * 1e3 * 64 / B, 4), "frames_per_s": round(B / med, 1),
+            "keypoints_per_s": round(float(counts.sum()) / med, 1), "pcie_bytes_per_batch": int(frames_np.nbytes + counts.sum() * 60 + 8 * B)}
 
-    import torch
+
+def extra_config3(pkg, torch, shard, synth, device, steps=20, warmup=3):
+    """BASELINE configs[2]: 1920x1080, nFeatures=4000, extract + dense match against the previous frame; 8 frames per step."""
+    W, H, NF, B = 1920, 1080, 4000, 8
+    frames = torch.from_numpy(synth.stream(2, W, H, B)).cuda()
+    st = torch.cuda.Stream()
+    p = DevicePath(pkg, torch, shard, frames, W, H, B, NF, device, True, stream=st)
+    with torch.cuda.stream(st):
+        for _ in range(warmup):
+            p.step()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            p.step()
+        torch.cuda.synchronize()
+        el = (time.perf_counter() - t0) / steps
+    _, _, _, counts, nmatch = p.layout.views(p.bufs[0])
+    if int(p.status.abs().sum().item()) != 0:
+        raise RuntimeError("device status nonzero")
+    nk = int(counts[1:].sum().item())
+    p.ex.set_profiling(True)
+    import numpy as np
+    acc = np.zeros(4)
+    for _ in range(3):
+        p.extract_into(p.bufs[0], st.cuda_stream)
+        acc += p.ex.stage_ms()
+    p.ex.set_profiling(False)
+    acc /= 3
+    ab = algorithmic_bytes(W, H, 8, nk / B, 0, 0, 0)
+    whole = (ab["pyramid"] + ab["fast"] + ab["describe"]) * B / el / 1e9
+    return {"workload": "8 x 1920x1080 nFeatures=4000, extract + dense match vs previous frame (BASELINE configs[2]), resident in HBM",
+            "steps": steps, "ms_per_step": round(el * 1e3, 4), "frames_per_s": round(B / el, 1), "keypoints_per_s": round(nk / el, 1),
+            "keypoints_per_frame": round(nk / B, 1), "matches_per_step": int(nmatch[2:].sum().item()),
+            "stage_ms": {k: round(float(v), 4) for k, v in zip(("pyramid", "fast", "quadtree", "describe"), acc)},
+            "whole_path_algorithmic_GBps": round(whole, 1), "frac_of_hbm_peak": round(whole / 8000.0, 4)}
+
+
+def main():
+    args = parse_args()
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        sys.exit(launch_ranks(args))
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        print("bench.py: --gpus %d but the launcher started WORLD_SIZE=%d ranks" % (args.gpus, world), file=sys.stderr)
+        sys.exit(2)
+
+    import numpy as np
+    import torch
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: liborbx has no CPU path")
     ndev = torch.cuda.device_count()
-    local = local % max(ndev, 1)          # rehearsal with more ranks than GPUs (ORBX_BENCH_BACKEND=gloo)
+    backend = os.environ.get("ORBX_BENCH_BACKEND", "nccl")   # "gloo": rehearsal of the N-rank path on fewer GPUs than ranks
+    if backend == "nccl" and world > ndev:
+        raise SystemExit("bench.py: %d ranks but %d GPU(s) visible (set ORBX_BENCH_BACKEND=gloo to rehearse on fewer)" % (world, ndev))
+    local = local % max(ndev, 1)
     torch.cuda.set_device(local)
     dist = None
-    backend = os.environ.get("ORBX_BENCH_BACKEND", "nccl")
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -215,79 +340,82 @@ def main():
             dist.init_process_group(backend, rank=rank, world_size=world)
 
     pkg = load_pkg()
+    import my_slam_amd.shard as shard
     import my_slam_amd.synth as synth
-    W, H, B, NF = args.width, args.height, args.batch, args.nfeatures
-    do_match = not args.no_match and B > 1
-
-    # synthetic TUM-mono-like stream, a different canvas per rank
-    frames_np = synth.stream(4 + rank, W, H, B)
+    W, H, NF = args.width, args.height, args.nfeatures
+    # ONE synthetic TUM-mono-like stream; every rank takes its contiguous block of it
+    total = args.batch * world if args.scaling == "weak" else args.batch
+    if total < world:
+        raise SystemExit("bench.py: %d frames cannot be split over %d ranks" % (total, world))
+    ranges = [shard.shard_range(total, world, r) for r in range(world)]
+    lo, hi = ranges[rank]
+    B = shard.max_shard(total, world)                 # block capacity (identical on every rank: one gather size)
+    nown = hi - lo
+    do_match = not args.no_match and total > 1
+    frames_np = synth.stream(4, W, H, total, first=lo, count=nown)
     frames = torch.from_numpy(frames_np).cuda()
-    ex = pkg.ORBextractor(NF, 1.2, 8, 20, 7, device=local, max_width=W, max_height=H, max_batch=B)
-    if args.subbatches:
-        ex.set_subbatches(args.subbatches)
-    if args.no_overlap:
-        ex.set_overlap_pyramid(False)
-    cap = ex.cap
-    # One flat result buffer per pipeline slot: [B][cap] 28-B keypoints | [B][cap][32] descriptors | [B] counts,
-    # so that one gather moves a whole step's results.  Two slots: the gather of step i overlaps step i+1.
-    nb_k, nb_d = B * cap * 28, B * cap * 32
-    nbytes = nb_k + nb_d + B * 4
-    nslot = 2 if world > 1 else 1
-    outbuf = [torch.zeros(nbytes, dtype=torch.uint8, device="cuda") for _ in range(nslot)]
-    kps_v = [o[:nb_k].view(torch.float32).view(B, cap, 7) for o in outbuf]
-    desc_v = [o[nb_k:nb_k + nb_d].view(B, cap, 32) for o in outbuf]
-    cnt_v = [o[nb_k + nb_d:].view(torch.int32) for o in outbuf]
-    kps, desc, counts = kps_v[0], desc_v[0], cnt_v[0]
-    status = torch.zeros(B, dtype=torch.int32, device="cuda")
-    matcher = pkg.ORBmatcher(0.9, True, device=local, max_queries=cap, max_train=cap, max_pairs=1) if do_match else None
-    match12 = torch.full((B, cap), -1, dtype=torch.int32, device="cuda")
-    nmatch = torch.zeros(B, dtype=torch.int32, device="cuda")
-    gather_bufs = None
-    if world > 1 and rank == 0:
-        gather_bufs = [[torch.empty_like(outbuf[0], device="cuda" if backend == "nccl" else "cpu") for _ in range(world)]
-                       for _ in range(nslot)]
-    pending = [None] * nslot
 
-    # one explicit (non-default) stream carries the whole path, so extract -> match -> gather are
+    # one explicit (non-default) stream carries the whole path, so extract -> exchange -> match -> gather are
     # ordered by the stream itself (a NULL stream would select each handle's private stream)
     stream = torch.cuda.Stream()
     torch.cuda.set_stream(stream)
-    s = stream.cuda_stream
-    assert s != 0
+    assert stream.cuda_stream != 0
+    nslot = 2 if world > 1 else 1                     # two result blocks: the gather of step i overlaps step i+1
+    path = DevicePath(pkg, torch, shard, frames, W, H, B, NF, local, do_match, rank, world, nslot, stream)
+    path.nown = nown
+    ex, cap, layout = path.ex, path.cap, path.layout
+    if args.subbatches:
+        ex.set_subbatches(args.subbatches)
+    on_gpu = backend == "nccl"
+    gather_bufs = None
+    if world > 1 and rank == 0:
+        gather_bufs = [[torch.empty(layout.nbytes, dtype=torch.uint8, device="cuda" if on_gpu else "cpu") for _ in range(world)]
+                       for _ in range(nslot)]
+    # gloo rehearsal: communication goes through a host mirror of the block
+    mirror = [torch.empty(layout.nbytes, dtype=torch.uint8) for _ in range(nslot)] if (world > 1 and not on_gpu) else None
+    pending = [None] * nslot
+    sends = [[] for _ in range(nslot)]
     step_no = [0]
 
     def step():
         k = step_no[0] % nslot
         step_no[0] += 1
-        if pending[k] is not None:         # the gather that last read this slot must be done before it is rewritten
+        if pending[k] is not None:         # the gather that last read this block must be done before it is rewritten
             pending[k].wait()
             pending[k] = None
-        kp, de, cn = kps_v[k], desc_v[k], cnt_v[k]
-        ex.extract_batch_device(frames.data_ptr(), B, W, H, frames.stride(1), frames.stride(0),
-                                kp.data_ptr(), de.data_ptr(), cn.data_ptr(), status.data_ptr(), s)
-        if do_match:   # frame k (query) against frame k-1 (train), k = 1..B-1
-            matcher.match_batch_device(de.data_ptr() + cap * 32, kp.data_ptr() + cap * 28, cn.data_ptr() + 4,
-                                       de.data_ptr(), kp.data_ptr(), cn.data_ptr(), cap, B - 1,
-                                       match12.data_ptr() + cap * 4, nmatch.data_ptr() + 4, stream=s)
-        if world > 1:  # RCCL over xGMI: results back to rank 0, nothing else crosses GPUs
-            if backend == "nccl":
-                pending[k] = dist.gather(outbuf[k], gather_bufs[k] if rank == 0 else None, dst=0, async_op=True)
-            else:          # CPU rehearsal of the same plumbing (gloo has no GPU gather)
-                stream.synchronize()
-                dist.gather(outbuf[k].cpu(), gather_bufs[k] if rank == 0 else None, dst=0)
+        for w in sends[k]:
+            w.wait()
+        comm = None
+        if mirror is not None:
+            def stage_out(k=k):
+                stream.synchronize(); mirror[k].copy_(path.bufs[k])
+            def stage_in(k=k):
+                kv, dv, _, cv, _ = layout.views(path.bufs[k]); km, dm, _, cm, _ = layout.views(mirror[k])
+                kv[0].copy_(km[0]); dv[0].copy_(dm[0]); cv[0:1].copy_(cm[0:1])
+            comm = {"comm_buf": mirror[k], "stage_out": stage_out, "stage_in": stage_in}
+        sends[k] = path.step(k, comm=comm)
+        if world > 1:                      # RCCL over xGMI: the block goes back to rank 0, nothing else crosses GPUs
+            if on_gpu:
+                pending[k] = shard.gather_flat(path.bufs[k], gather_bufs[k] if rank == 0 else None, async_op=True)
+            else:
+                stream.synchronize(); mirror[k].copy_(path.bufs[k])
+                shard.gather_flat(mirror[k], gather_bufs[k] if rank == 0 else None)
 
     def drain():
         for k in range(nslot):
             if pending[k] is not None:
                 pending[k].wait()
                 pending[k] = None
+            for w in sends[k]:
+                w.wait()
+            sends[k] = []
 
     for _ in range(args.warmup):
         step()
     drain()
     torch.cuda.synchronize()
-    if int(status.abs().sum().item()) != 0:
-        raise SystemExit("device status nonzero: %s" % status.tolist())
+    if int(path.status.abs().sum().item()) != 0:
+        raise SystemExit("device status nonzero: %s" % path.status.tolist())
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
@@ -304,53 +432,60 @@ def main():
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if on_gpu else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     step_ms = sorted(evs[i].elapsed_time(evs[i + 1]) for i in range(args.steps))
-    p50_ms = step_ms[len(step_ms) // 2]
-    nk_local = int(counts.sum().item())
-    nm_local = int(nmatch.sum().item()) if do_match else 0
-    tot = torch.tensor([nk_local, nm_local], dtype=torch.int64, device="cuda" if (world == 1 or backend == "nccl") else "cpu")
+    pct = lambda q: step_ms[min(len(step_ms) - 1, int(q * len(step_ms)))]
+    kps_v, desc_v, m12_v, counts_v, nmatch_v = layout.views(path.bufs[0])
+    nk_local = int(counts_v[1:nown + 1].sum().item())
+    nm_local = int(nmatch_v[(2 if rank == 0 else 1):nown + 1].sum().item()) if do_match else 0
+    tot = torch.tensor([nk_local, nm_local], dtype=torch.int64, device="cuda" if (world == 1 or on_gpu) else "cpu")
     if world > 1:
         dist.all_reduce(tot)
     nk_all, nm_all = int(tot[0].item()), int(tot[1].item())
+    gathered_ok = None
+    if world > 1 and rank == 0:   # what rank 0 holds after the last gather is the whole stream's result
+        last = (step_no[0] - 1) % nslot
+        gk = sum(int(layout.views(gather_bufs[last][r])[3][1:ranges[r][1] - ranges[r][0] + 1].sum().item()) for r in range(world))
+        gathered_ok = gk == nk_all
+        if not gathered_ok:
+            raise SystemExit("gathered block holds %d keypoints, the ranks produced %d" % (gk, nk_all))
 
     # ---- per-stage GPU time (HIP events on the launch stream, inside the library) ----
     roof = None
     stage = {}
+    s = stream.cuda_stream
     if rank == 0:
         ex.set_profiling(True)
         acc = np.zeros(4)
         tm = 0.0
         reps = max(3, min(10, args.steps))
+        npairs = nown - 1
         for _ in range(reps):
-            ex.extract_batch_device(frames.data_ptr(), B, W, H, frames.stride(1), frames.stride(0),
-                                    kps.data_ptr(), desc.data_ptr(), counts.data_ptr(), status.data_ptr(), s)
+            path.extract_into(path.bufs[0], s)
             acc += ex.stage_ms()
-            if do_match:
+            if do_match and npairs > 0:
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record()
-                matcher.match_batch_device(desc.data_ptr() + cap * 32, kps.data_ptr() + cap * 28, counts.data_ptr() + 4,
-                                           desc.data_ptr(), kps.data_ptr(), counts.data_ptr(), cap, B - 1,
-                                           match12.data_ptr() + cap * 4, nmatch.data_ptr() + 4, stream=s)
+                path.match_slots(path.bufs[0], 2, npairs, s)
                 e1.record()
                 torch.cuda.synchronize()
                 tm += e0.elapsed_time(e1)
         ex.set_profiling(False)
         acc /= reps
         stage = {"pyramid": acc[0], "fast": acc[1], "quadtree": acc[2], "describe": acc[3]}
-        if do_match:
+        if do_match and npairs > 0:
             stage["match"] = tm / reps
         ncand = sum(len(ex.candidates(0, l)) for l in range(8))   # frame 0's candidates, representative
-        nkf = nk_local / B
+        nkf = nk_local / nown
         ab = algorithmic_bytes(W, H, 8, nkf, ncand, nkf, nkf)
         dom = max(stage, key=lambda k: stage[k])
-        nunits = (B - 1) if dom == "match" else B
+        nunits = npairs if dom == "match" else nown
         achieved = ab[dom] * nunits / (stage[dom] * 1e-3) / 1e9
         traffic = None
         tf = os.path.join(ROOT, "profiles", "traffic.json")
-        if os.path.exists(tf):
+        if os.path.exists(tf) and (W, H, NF, nown) == (640, 480, 1000, 64):   # the PMC passes were taken on this workload
             try:
                 traffic = json.load(open(tf)).get(dom)
             except Exception:
@@ -373,47 +508,70 @@ def main():
                 "avg_launch_ms": round(stage[dom], 4),
                 "measured_copy_GBps": round(copy_gbps, 1), "frac_of_measured_copy": round(achieved / copy_gbps, 5),
                 "stage_ms": {k: round(float(v), 4) for k, v in stage.items()},
-                "whole_path_algorithmic_GBps": round(sum(ab[k] for k in ("pyramid", "fast", "describe")) * B * world
+                "whole_path_algorithmic_GBps": round(sum(ab[k] for k in ("pyramid", "fast", "describe")) * total
                                                      / (elapsed / args.steps) / 1e9, 2)}
 
-    # ---- extra (N = 1): the same steps pipelined over two HIP streams, one captured HIP graph per step ----
-    # Consecutive steps are independent, so the short latency-bound kernels of one step (resize chain, quadtree, acceptance)
-    # can run underneath the VALU-bound ones of the next.  Reported beside the contract's single-stream line, never as `value`:
-    # kernels of overlapping steps time-share the GPU, so per-kernel durations (and `roofline`) are not defined in that mode.
-    pipelined = None
-    if rank == 0 and world == 1 and not args.no_pipelined:
-        try:
-            pipelined = pipelined_pass(pkg, torch, frames, W, H, B, NF, local, do_match, args.steps, nk_local, args.pipelined_streams)
-        except Exception as e:
-            pipelined = {"error": str(e)[:200]}
-
-    cpu = None
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        cpu = cpu_baseline(frames_np, NF, args.cpu_budget)
+    # ---- extras (N = 1 only; reported beside the contract's line, never as `value`) ----
+    pipelined = host_api = extra = cpu = None
+    if rank == 0 and world == 1:
+        # the same steps pipelined over two HIP streams, one captured HIP graph per step: consecutive steps are independent, so
+        # the short latency-bound kernels of one step run underneath the VALU-bound ones of the next.  Kernels of overlapping
+        # steps time-share the GPU, so per-kernel durations (and `roofline`) are not defined in that mode.
+        if not args.no_pipelined:
+            try:
+                pipelined = pipelined_pass(pkg, torch, shard, frames, W, H, B, NF, local, do_match, args.steps, nk_local, args.pipelined_streams)
+            except Exception as e:
+                pipelined = {"error": str(e)[:200]}
+        if not args.no_host_api:
+            try:
+                host_api = host_api_pass(pkg, frames_np, W, H, NF, local)
+            except Exception as e:
+                host_api = {"error": str(e)[:200]}
+        if not args.no_extra_configs:
+            try:
+                extra = [extra_config3(pkg, torch, shard, synth, local)]
+            except Exception as e:
+                extra = [{"error": str(e)[:200]}]
+        if not args.no_cpu_baseline:
+            cpu = cpu_baseline(frames_np, NF, args.cpu_budget)
 
     if rank == 0:
         ms = elapsed / args.steps * 1e3
+        if world == 1:
+            par = "1 GPU, no communication"
+        else:
+            par = ("one stream of %d frames cut into %d contiguous blocks, one rank per GPU; per step one boundary frame to the next rank "
+                   "(send/recv) and one gather of the keypoint/descriptor/match block to rank 0; backend %s%s"
+                   % (total, world, backend, " = RCCL over xGMI" if on_gpu else " (CPU rehearsal of the plumbing, host mirrors)"))
         out = {
-            "metric": "ORB keypoints/s + frames/s, 1000 feats/frame @640x480, 1/2/4/8 GPU",
+            "metric": METRIC,
             "value": round(nk_all / (elapsed / args.steps), 1),
             "unit": "keypoints/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(ms, 4), "ms_per_step_p50_gpu": round(p50_ms, 4), "higher_is_better": True, "scaling": "weak",
+            "ms_per_step": round(ms, 4), "higher_is_better": True, "scaling": args.scaling,
             "vs_baseline": None, "dtype": "u8", "data": "synthetic",
-            "frames_per_s": round(B * world / (elapsed / args.steps), 1),
+            "frames_per_s": round(total / (elapsed / args.steps), 1),
+            "timed_region_s": round(elapsed, 5),
+            "ms_per_step_gpu": {"p10": round(pct(0.1), 4), "p50": round(pct(0.5), 4), "p90": round(pct(0.9), 4), "rank": 0},
             "matches_per_step": nm_all,
-            "keypoints_per_frame": round(nk_all / (B * world), 2),
-            "config": {"workload": "%dx%d nFeatures=%d 8 levels scale 1.2 (BASELINE configs[1] shape), batch of %d frames per GPU "
+            "keypoints_per_frame": round(nk_all / total, 2),
+            "config": {"workload": "%dx%d nFeatures=%d 8 levels scale 1.2 (BASELINE configs[1] shape), %d frames per step%s "
                                    "(configs[3] stream), extract%s; inputs resident in HBM"
-                                   % (W, H, NF, B, " + dense match vs previous frame (ratio 0.9, TH_LOW, rotation filter)" if do_match else ""),
-                       "frames_per_gpu": B, "width": W, "height": H, "nfeatures": NF,
-                       "parallelism": "frames sharded over %d GPU(s); RCCL gather of keypoint/descriptor buffers to rank 0" % world},
+                                   % (W, H, NF, total, " (%d per GPU)" % B if world > 1 else "",
+                                      " + dense match vs previous frame (ratio 0.9, TH_LOW, rotation filter)" if do_match else ""),
+                       "frames_per_step": total, "frames_per_gpu": B, "width": W, "height": H, "nfeatures": NF,
+                       "parallelism": par},
             "roofline": roof,
             "cpu_baseline": cpu,
+            "host_api": host_api,
+            "extra_configs": extra,
             "pipelined": pipelined,
         }
+        if gathered_ok is not None:
+            out["gathered_on_rank0"] = gathered_ok
         print(json.dumps(out))
     if world > 1:
+        dist.barrier()
         dist.destroy_process_group()
 
 

@@ -15,7 +15,8 @@ import subprocess
 import numpy as np
 
 PKG_DIR = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(PKG_DIR, "lib", "liborbx.so")
+# ORBX_LIB: developer switch for A/B builds of the same library (tools/dbg/ab_variants.sh); never a different back end
+LIB_PATH = os.environ.get("ORBX_LIB") or os.path.join(PKG_DIR, "lib", "liborbx.so")
 
 KP_DTYPE = np.dtype([("x", "<f4"), ("y", "<f4"), ("size", "<f4"), ("angle", "<f4"),
                      ("response", "<f4"), ("octave", "<i4"), ("class_id", "<i4")])
@@ -303,6 +304,17 @@ class ORBextractor:
         _chk(self.L.orbx_extract_batch(self.h, _p(images), B, W, H, images.strides[1], images.strides[0],
                                        _p(kps), _p(desc), self.cap, _p(counts)))
         return [(kps[k, :counts[k]].copy(), desc[k, :counts[k]].copy()) for k in range(B)]
+
+    def extract_batch_raw(self, images):
+        """orbx_extract_batch without the per-frame slicing: (kps [B,cap], desc [B,cap,32], counts [B])."""
+        images = np.ascontiguousarray(images, dtype=np.uint8)
+        B, H, W = images.shape
+        if getattr(self, "_raw", None) is None or self._raw[0].shape[0] != B:
+            self._raw = (np.zeros((B, self.cap), KP_DTYPE), np.zeros((B, self.cap, 32), np.uint8), np.zeros(B, np.int32))
+        kps, desc, counts = self._raw
+        _chk(self.L.orbx_extract_batch(self.h, _p(images), B, W, H, images.strides[1], images.strides[0],
+                                       _p(kps), _p(desc), self.cap, _p(counts)))
+        return kps, desc, counts
 
     def extract_batch_device(self, d_images_ptr, B, W, H, row_stride, frame_stride,
                              d_kps_ptr, d_desc_ptr, d_counts_ptr, d_status_ptr, stream=None):

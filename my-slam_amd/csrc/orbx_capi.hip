@@ -140,8 +140,17 @@ static int make_plan(const orbx_extractor *h, int W, int H, OrbxPlan *P, std::st
             if (L.nIni <= 0) { *why = "portrait level (quadtree root count 0): undefined in the reference"; return ORBX_E_SHAPE; }
             L.hX = width / L.nIni;
         }
-        const long long zone = (long long)std::max(L.w - 2 * ORBX_EDGE, 0) * std::max(L.h - 2 * ORBX_EDGE, 0);
-        L.cand_cap = L.nCols > 0 ? (int)std::min<long long>(zone / 8 + 256, (1 << 20) - 1) : 0;
+        // Candidate capacity = the most NMS survivors a level can have, so that no image overflows it (the reference has no
+        // such limit): survivors are strict 8-neighbour maxima inside a cell's zone (cv::FAST nonmax, per cell :811-817), no
+        // two of them are adjacent, so a zw x zh zone holds at most ceil(zw/2) * ceil(zh/2); the zones of a level's cells tile
+        // [19, w-19) x [19, h-19), hence sum <= ceil((w-38+nCols)/2) * ceil((h-38+nRows)/2) (monotone in w and h, so a
+        // smaller frame always fits the workspace planned for the handle's maximum).  The quadtree packs a candidate index
+        // into 20 bits: only a level beyond ~4.1 M pixels can still report ORBX_E_CAND_OVERFLOW.
+        const long long zw_all = std::max(L.w - 2 * ORBX_EDGE, 0), zh_all = std::max(L.h - 2 * ORBX_EDGE, 0);
+        const long long zone = zw_all * zh_all;
+        const long long nmax = ((zw_all + L.nCols + 1) / 2) * ((zh_all + L.nRows + 1) / 2);
+        L.cand_cap = L.nCols > 0 ? (int)std::min<long long>(nmax + 64, (1 << 20) - 1) : 0;
+        if (L.nCols > 0 && zone / 8 + 256 >= 100000) P->oct_big = 1;   // 1080p-class level: the quadtree runs 1024-thread workgroups
         L.cand_off = cand_off; cand_off += (L.cand_cap + 15) / 16 * 16;
         L.list_cap = L.nCols > 0 ? (std::max(L.quota + 3, 4 * L.nIni) + 1 + 3) / 4 * 4 : 0;
         L.list_off = list_off; list_off += L.list_cap;

@@ -26,6 +26,9 @@
 #ifndef FAST_REJECT_POINTS
 #define FAST_REJECT_POINTS 4   // stage-1 reject on 4 or 8 circle points (both necessary conditions; results identical)
 #endif
+#ifndef FAST_QUEUE_ROWMAJOR
+#define FAST_QUEUE_ROWMAJOR 1
+#endif
 #define FAST_PADL 4      // left pad (bytes) of every tile row so that dword g-1 exists for every group
 #define FAST_CLIST 224   // corners listed per cell before NMS falls back to scanning the whole score map
 
@@ -304,8 +307,15 @@ __global__ __launch_bounds__(FAST_THREADS) void k_fast_cells(OrbxPlan plan, Orbx
             const unsigned long long b2 = BAL(f2) & BAL(h2), b3 = BAL(f3) & BAL(h3);
 #undef BAL
             const int n0 = __popcll(b0), n1 = __popcll(b1), n2 = __popcll(b2);
+#if FAST_QUEUE_ROWMAJOR
+            // queue in the zone's row-major pixel order: entry = survivors of lower lanes (all four pixels) + own lower pixels.
+            // Neighbouring lanes of stage 2 then gather from neighbouring LDS addresses (bank conflicts: DESIGN.md §4).
+            const int e0 = orbx_prefix_cnt(b3, orbx_prefix_cnt(b2, orbx_prefix_cnt(b1, orbx_prefix_cnt(b0, qn))));
+            const int e1 = e0 + (k0 ? 1 : 0), e2 = e1 + (k1 ? 1 : 0), e3 = e2 + (k2 ? 1 : 0);
+#else
             const int e0 = orbx_prefix_cnt(b0, qn), e1 = orbx_prefix_cnt(b1, qn + n0);
             const int e2 = orbx_prefix_cnt(b2, qn + n0 + n1), e3 = orbx_prefix_cnt(b3, qn + n0 + n1 + n2);
+#endif
             const int pz = (zy << 6) + zx0;          // (zy << 6) | zx for every pixel with 0 <= zx < 64
             S.queue[k0 ? e0 : 383] = (uint16_t)pz;
             S.queue[k1 ? e1 : 383] = (uint16_t)(pz + 1);

@@ -90,6 +90,7 @@ struct OrbxPlan {
     int ini_th, min_th;
     int ncells;                   // cells per frame over all levels
     int blur_mode;
+    int oct_big;                  // some level is 1080p-class (tens of thousands of candidates): quadtree workgroups of 1024 threads
     int out_cap;                  // per-frame output capacity
     long long cand_frame;         // candidates per frame (elements)
     long long list_frame;         // sel entries per frame

@@ -535,9 +535,7 @@ size_t orbx_octree_lds_bytes(int list_cap_max) { return (size_t)list_cap_max * 8
 void orbx_launch_octree(const OrbxPlan &plan, const OrbxWork &wk, int nframes, size_t lds_bytes, hipStream_t s)
 {
     dim3 grid(plan.nlevels, nframes);
-    int big = 0;
-    for (int l = 0; l < plan.nlevels; l++) big = max(big, plan.lv[l].cand_cap);
-    if (big >= 100000) {   // 1080p-class levels: tens of thousands of keys per level
+    if (plan.oct_big) {   // 1080p-class levels: tens of thousands of keys per level
         if (lds_bytes > 32 * 1024)
             (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_octree<1024>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
         hipLaunchKernelGGL(k_octree<1024>, grid, dim3(1024), lds_bytes, s, plan, wk);

@@ -67,18 +67,21 @@ def texture(seed, W, H, block_sizes=(7, 13, 29, 61), rect_density=0.004):
     return img
 
 
-def stream(seed, W, H, nframes, step=(2, 1), noise_seed0=100, noise=2):
-    """nframes x H x W uint8: canvas T(seed) cropped at offset k*step plus +-noise gray."""
+def stream(seed, W, H, nframes, step=(2, 1), noise_seed0=100, noise=2, first=0, count=None):
+    """nframes x H x W uint8: canvas T(seed) cropped at offset k*step plus +-noise gray.
+    first/count: only frames [first, first+count) of that nframes-long stream (a rank's shard of it)."""
     pad_x, pad_y = step[0] * (nframes - 1), step[1] * (nframes - 1)
     canvas = texture(seed, W + pad_x, H + pad_y)
-    out = np.empty((nframes, H, W), dtype=np.uint8)
-    for k in range(nframes):
+    count = nframes - first if count is None else count
+    out = np.empty((count, H, W), dtype=np.uint8)
+    for j in range(count):
+        k = first + j
         ox, oy = step[0] * k, step[1] * k
         crop = canvas[oy:oy + H, ox:ox + W].astype(np.int16)
         if noise > 0:
             r = splitmix64(noise_seed0 + k, W * H)
             crop = crop + (r % np.uint64(2 * noise + 1)).astype(np.int16).reshape(H, W) - noise
-        out[k] = np.clip(crop, 0, 255).astype(np.uint8)
+        out[j] = np.clip(crop, 0, 255).astype(np.uint8)
     return out
 
 

@@ -13,15 +13,20 @@ W, H, n, B = (int(a) for a in sys.argv[1:5])
 fr = synth.stream(3, W, H, B)
 e = M.ORBextractor(n, max_width=W, max_height=H, max_batch=B)
 L = M.lib()
-for fn in (L.orbx_debug_fast_trace, L.orbx_debug_desc_trace):
-    fn.argtypes = [C.c_void_p, C.c_int]
+have = [nm for nm in ("orbx_debug_fast_trace", "orbx_debug_desc_trace") if hasattr(L, nm)]
+for nm in have:
+    getattr(L, nm).argtypes = [C.c_void_p, C.c_int]
 e.extract_batch(fr)
 buf = (C.c_ulonglong * 8)()
-L.orbx_debug_fast_trace(buf, 1); L.orbx_debug_desc_trace(buf, 1)
+for nm in have:
+    getattr(L, nm)(buf, 1)
 e.extract_batch(fr)
 torch.cuda.synchronize()
-for name, fn, ph in (("fast", L.orbx_debug_fast_trace, ["header + tile load", "stage 1 (reject + queue)", "stage 2 (scores)", "NMS", "output"]),
-                     ("describe", L.orbx_debug_desc_trace, ["header + patch load", "IC angle", "blur rows", "blur columns", "sincos + rBRIEF + store"])):
+for name, nm, ph in (("fast", "orbx_debug_fast_trace", ["header + tile load", "stage 1 (reject + queue)", "stage 2 (scores)", "NMS", "output"]),
+                     ("describe", "orbx_debug_desc_trace", ["header + patch load", "IC angle", "blur rows", "blur columns", "sincos + rBRIEF + store"])):
+    if nm not in have:
+        continue
+    fn = getattr(L, nm)
     assert fn(buf, 0) == 0
     tot = sum(buf[i] for i in range(6)); waves = buf[7]
     print(f"{name}: {waves} waves, {tot / max(waves, 1):.0f} clocks per wave")
