@@ -148,6 +148,33 @@ int orbm_search_by_projection_map(orbm_matcher *m, int n_mp, const uint8_t *in_v
                                   int32_t *cur_obs, int32_t *cur_match, int *nmatches);
 
 /*
+ * ORBmatcher::SearchByProjection(Frame &CurrentFrame, KeyFrame *pKF, const set<MapPoint*> &sAlreadyFound, th, ORBdist)
+ * (src/ORBmatcher.cc:1472-1599), the matcher Tracking::Relocalization runs after PnP (src/Tracking.cc:1459, 1473: th = 10,
+ * ORBdist = 100, then th = 3, ORBdist = 64).  Three entry points, because the level prediction in the middle belongs to the
+ * caller's MapPoint (MapPoint::PredictScale reads the protected mfMaxDistance, src/MapPoint.cc:402-417):
+ *   orbm_project_points   (host) :1498-1514 for n world points: x3Dc = Rcw x + tcw, u, v, 1 / zc, the image-bounds test
+ *                         (in_image[i], :1507-1510) and dist3D = |x - Ow| -- cv::Mat algebra as OpenCV's float GEMM does it
+ *                         (double accumulation, one rounding), cv::norm accumulating in double.  invzc and dist3d may be NULL.
+ *   orbm_predict_scale    (host) MapPoint::PredictScale(dist, Frame*) for callers that own mfMaxDistance themselves.
+ *   orbm_search_by_projection_kf   the search: per key-frame MapPoint i, use[i] = usable (non-NULL, !isBad(), not in sAlreadyFound,
+ *                         in_image, minDistance <= dist3D <= maxDistance :1492-1521), window (proj_u, proj_v, th *
+ *                         mvScaleFactors[pred_level], levels pred_level -+ 1 :1526-1528), best distance over the free slots
+ *                         (cur_has_point[i2] == 0, :1541-1542), accept at <= orb_dist, rotation histogram with
+ *                         kf_angle[i] = pKF->mvKeysUn[i].angle and the ComputeThreeMaxima cull (:1577-1596).  The current frame's
+ *                         grid must be in the handle.  cur_has_point in/out; cur_match[i2] = i or -1; *nmatches = return value.
+ * Windows and candidate distances on the GPU in two passes, the scan on the host (it is sequential in the reference: an
+ * assignment blocks the slot for every later MapPoint).
+ */
+int orbm_project_points(const float *Tcw, float fx, float fy, float cx, float cy, const float bounds[4],
+                        const float *xw, int n, float *u, float *v, float *invzc, float *dist3d, uint8_t *in_image);
+int orbm_predict_scale(float mf_max_distance, float current_dist, float log_scale_factor, int n_levels);
+int orbm_search_by_projection_kf(orbm_matcher *m, int n_mp, const uint8_t *use, const float *proj_u, const float *proj_v,
+                                 const int32_t *pred_level, const uint8_t *mp_desc, const float *kf_angle,
+                                 const float *scale_factors, int nlevels, const orbx_keypoint *kps_cur, const uint8_t *desc_cur,
+                                 int n_cur, float th, int orb_dist, int check_orientation,
+                                 uint8_t *cur_has_point, int32_t *cur_match, int *nmatches);
+
+/*
  * Frame::UndistortKeyPoints (src/Frame.cc:404-434) and Frame::ComputeImageBounds (:436-463): host code, they run once per
  * frame on ~10^3 points between orbx_extract and orbm_grid_build.  dist = mDistCoef (k1, k2, p1, p2[, k3]); ndist = 4 or 5.
  * With dist[0] == 0 both are the identity exactly as in the reference (:406-410, :455-461).  Otherwise the points go

@@ -54,8 +54,10 @@ typedef struct orbx_extractor orbx_extractor;
 enum {
     ORBX_OPT_BLUR_ROUNDING = 1, /* 0: OpenCV portable C column pass (default); 1: OpenCV x86 SSE2 column pass */
     ORBX_OPT_OVERLAP_PYRAMID = 3, /* 0/1 (default 0; measured slower on MI355X): resize chain on a side stream underneath FAST on level 0 */
-    ORBX_OPT_SUBBATCHES = 2     /* 1..4 (default 1): batches of >= 16 frames are cut into this many sub-batches on
+    ORBX_OPT_SUBBATCHES = 2,    /* 1..4 (default 1): batches of >= 16 frames are cut into this many sub-batches on
                                    separate HIP streams so latency-bound and VALU-bound kernels overlap */
+    ORBX_OPT_BATCH_CHUNK = 4    /* frames per chunk of orbx_extract_batch's upload / extract / download pipeline (default 16;
+                                   0 = the whole batch in one piece) */
 };
 
 /*

@@ -27,6 +27,7 @@ ORBX_E_INVALID, ORBX_E_CAPACITY, ORBX_E_SHAPE, ORBX_E_HIP, ORBX_E_CAND_OVERFLOW,
 ORBX_OPT_BLUR_ROUNDING = 1
 ORBX_OPT_SUBBATCHES = 2
 ORBX_OPT_OVERLAP_PYRAMID = 3
+ORBX_OPT_BATCH_CHUNK = 4
 
 
 class OrbxError(RuntimeError):
@@ -172,6 +173,13 @@ def _bind_matcher(L):
     L.orbm_search_by_projection_map.argtypes = [vp, C.c_int, vp, vp, vp, vp, vp, vp, vp, vp, vp, C.c_int, vp, vp, vp, C.c_int,
                                                 C.c_float, C.c_float, vp, vp, vp]
     L.orbm_search_by_projection_map.restype = C.c_int
+    L.orbm_project_points.argtypes = [vp, C.c_float, C.c_float, C.c_float, C.c_float, vp, vp, C.c_int, vp, vp, vp, vp, vp]
+    L.orbm_project_points.restype = C.c_int
+    L.orbm_predict_scale.argtypes = [C.c_float, C.c_float, C.c_float, C.c_int]
+    L.orbm_predict_scale.restype = C.c_int
+    L.orbm_search_by_projection_kf.argtypes = [vp, C.c_int, vp, vp, vp, vp, vp, vp, vp, C.c_int, vp, vp, C.c_int, C.c_float, C.c_int, C.c_int,
+                                               vp, vp, vp]
+    L.orbm_search_by_projection_kf.restype = C.c_int
     L.orbm_undistort_keypoints.argtypes = [vp, C.c_int, C.c_float, C.c_float, C.c_float, C.c_float, vp, C.c_int, vp]
     L.orbm_undistort_keypoints.restype = C.c_int
     L.orbm_image_bounds.argtypes = [C.c_int, C.c_int, C.c_float, C.c_float, C.c_float, C.c_float, vp, C.c_int, vp]
@@ -247,6 +255,10 @@ class ORBextractor:
     def set_subbatches(self, n):
         _chk(self.L.orbx_set_option(self.h, ORBX_OPT_SUBBATCHES, n))
 
+    def set_batch_chunk(self, frames):
+        """Frames per chunk of extract_batch's upload / extract / download pipeline (0 = one piece)."""
+        _chk(self.L.orbx_set_option(self.h, ORBX_OPT_BATCH_CHUNK, int(frames)))
+
     def set_overlap_pyramid(self, on):
         _chk(self.L.orbx_set_option(self.h, ORBX_OPT_OVERLAP_PYRAMID, int(on)))
 
@@ -306,8 +318,11 @@ class ORBextractor:
         return [(kps[k, :counts[k]].copy(), desc[k, :counts[k]].copy()) for k in range(B)]
 
     def extract_batch_raw(self, images):
-        """orbx_extract_batch without the per-frame slicing: (kps [B,cap], desc [B,cap,32], counts [B])."""
-        images = np.ascontiguousarray(images, dtype=np.uint8)
+        """orbx_extract_batch without the per-frame slicing: (kps [B,cap], desc [B,cap,32], counts [B]).  A row / frame
+        pitch larger than the width (a view into a bigger array) is passed through as it is."""
+        images = np.asarray(images, dtype=np.uint8)
+        if images.strides[2] != 1 or images.strides[1] < images.shape[2] or images.strides[0] < images.strides[1] * (images.shape[1] - 1) + images.shape[2]:
+            images = np.ascontiguousarray(images)
         B, H, W = images.shape
         if getattr(self, "_raw", None) is None or self._raw[0].shape[0] != B:
             self._raw = (np.zeros((B, self.cap), KP_DTYPE), np.zeros((B, self.cap, 32), np.uint8), np.zeros(B, np.int32))
@@ -507,6 +522,40 @@ class ORBmatcher:
         _mchk(self.L.orbm_search_by_projection_map(self.h, len(in_view), _p(in_view), _p(px), _p(py), _p(pxr), _p(lv), _p(vc), _p(mp_desc), _p(mp_obs),
                                                    _p(sf), len(sf), _p(kps_cur), _p(desc_cur), _p(ur), len(kps_cur), th, C.c_float(self.mfNNratio),
                                                    _p(cur_obs), _p(cm), C.byref(nm)))
+        return cm, nm.value
+
+    @staticmethod
+    def ProjectPoints(Tcw, K, bounds, xw):
+        """orbm_project_points: (u, v, invzc, dist3D, in_image) of world points under the pose Tcw (src/ORBmatcher.cc:1498-1514)."""
+        L = lib()
+        Tcw = np.ascontiguousarray(Tcw, np.float32).reshape(16); b = np.ascontiguousarray(bounds, np.float32)
+        xw = np.ascontiguousarray(xw, np.float32).reshape(-1, 3)
+        n = len(xw)
+        u, v, iz, d3 = (np.zeros(n, np.float32) for _ in range(4))
+        inside = np.zeros(n, np.uint8)
+        fx, fy, cx, cy = K
+        _mchk(L.orbm_project_points(_p(Tcw), fx, fy, cx, cy, _p(b), _p(xw), n, _p(u), _p(v), _p(iz), _p(d3), _p(inside)))
+        return u, v, iz, d3, inside
+
+    @staticmethod
+    def PredictScale(mf_max_distance, dist, log_scale_factor, n_levels):
+        L = lib()
+        return np.array([L.orbm_predict_scale(float(a), float(b), float(log_scale_factor), int(n_levels))
+                         for a, b in zip(np.asarray(mf_max_distance, np.float32), np.asarray(dist, np.float32))], np.int32)
+
+    def SearchByProjectionKF(self, use, proj_u, proj_v, pred_level, mp_desc, kf_angle, scale_factors, kps_cur, desc_cur, cur_has_point, th, orb_dist):
+        """ORBmatcher::SearchByProjection(Frame &CurrentFrame, KeyFrame *pKF, sAlreadyFound, th, ORBdist) (src/ORBmatcher.cc:1472-1599)
+        after the projection step; arguments as in include/orbm.h.  cur_has_point (uint8, in/out).  Returns (cur_match, nmatches)."""
+        f32 = lambda a: np.ascontiguousarray(a, np.float32)
+        use = np.ascontiguousarray(use, np.uint8); pu, pv, ka, sf = f32(proj_u), f32(proj_v), f32(kf_angle), f32(scale_factors)
+        lv = np.ascontiguousarray(pred_level, np.int32); mp_desc = np.ascontiguousarray(mp_desc, np.uint8).reshape(-1, 32)
+        kps_cur = np.ascontiguousarray(kps_cur); desc_cur = np.ascontiguousarray(desc_cur, np.uint8).reshape(-1, 32)
+        assert cur_has_point.dtype == np.uint8 and cur_has_point.flags["C_CONTIGUOUS"] and len(cur_has_point) == len(kps_cur)
+        cm = np.full(len(kps_cur), -1, np.int32)
+        nm = C.c_int(0)
+        _mchk(self.L.orbm_search_by_projection_kf(self.h, len(use), _p(use), _p(pu), _p(pv), _p(lv), _p(mp_desc), _p(ka), _p(sf), len(sf),
+                                                  _p(kps_cur), _p(desc_cur), len(kps_cur), th, int(orb_dist), 1 if self.mbCheckOrientation else 0,
+                                                  _p(cur_has_point), _p(cm), C.byref(nm)))
         return cm, nm.value
 
     def SearchForInitialization(self, kps1, desc1, kps2, desc2, prev_matched, windowSize=10):

@@ -461,6 +461,7 @@ extern "C" int orbm_create(orbm_matcher **out, int device, int max_queries, int 
     MHIPCHK(hipSetDevice(device));
     orbm_matcher *m = new orbm_matcher();
     m->device = device; m->max_q = max_queries; m->max_t = max_train; m->max_pairs = max_pairs;
+    { const char *e = getenv("ORBM_DENSE"); m->dense_popcount = e && !strcmp(e, "popcount"); }
     const size_t outn = std::max<size_t>((size_t)3 * max_queries, (size_t)max_pairs);
     if (hipMalloc((void **)&m->d_q, (size_t)max_queries * 32) != hipSuccess ||
         hipMalloc((void **)&m->d_t, (size_t)max_train * 32) != hipSuccess ||
@@ -533,11 +534,14 @@ extern "C" int orbm_best2(orbm_matcher *m, const uint8_t *q, int nq, const uint8
         if (total > 0) { int rc_ = orbm_h2d(m, m->d_idx, cand_idx, (size_t)total * 4, s); if (rc_ != ORBX_OK) return rc_; }
         hipLaunchKernelGGL(k_best2_csr, dim3((nq + 3) / 4), dim3(M_THREADS), 0, s, m->d_q, nq, m->d_t, m->d_off, m->d_idx, o_bi, o_bd, o_sd);
     } else {
-        const int S = pick_splits(nq, 1, nt);
+        const int S = m->dense_popcount ? pick_splits(nq, 1, nt) : orbm_mfma_splits(nq, nt, 1);
         int rc = ensure_partials(m, (size_t)S * nq);
         if (rc != ORBX_OK) return rc;
-        hipLaunchKernelGGL(k_best2_dense, dim3((nq + M_THREADS - 1) / M_THREADS, 1, S), dim3(M_THREADS), 0, s,
-                           m->d_q, (const int32_t *)nullptr, nq, m->d_t, (const int32_t *)nullptr, nt, 0LL, 0LL, nq, m->d_part);
+        if (m->dense_popcount)
+            hipLaunchKernelGGL(k_best2_dense, dim3((nq + M_THREADS - 1) / M_THREADS, 1, S), dim3(M_THREADS), 0, s,
+                               m->d_q, (const int32_t *)nullptr, nq, m->d_t, (const int32_t *)nullptr, nt, 0LL, 0LL, nq, m->d_part);
+        else if ((rc = orbm_launch_dense_mfma(m, m->d_q, nullptr, nq, m->d_t, nullptr, nt, 0LL, 0LL, nq, std::max(nt, 1), 1, nq, S, m->d_part, s)) != ORBX_OK)
+            return rc;
         hipLaunchKernelGGL(k_merge_best2, dim3((nq + M_THREADS - 1) / M_THREADS), dim3(M_THREADS), 0, s, m->d_part, S, nq, o_bi, o_bd, o_sd);
     }
     MHIPCHK(hipGetLastError());
@@ -587,11 +591,14 @@ extern "C" int orbm_distances(orbm_matcher *m, const uint8_t *q, int nq, const u
 static int launch_dense_batch(orbm_matcher *m, const uint8_t *d_q, const int32_t *d_nq, const uint8_t *d_t,
                               const int32_t *d_nt, int cap, int nbatch, hipStream_t s, int *S_out)
 {
-    const int S = pick_splits(cap, nbatch, cap);
+    const int S = m->dense_popcount ? pick_splits(cap, nbatch, cap) : orbm_mfma_splits(cap, cap, nbatch);
     int rc = ensure_partials(m, (size_t)(S + 1) * nbatch * cap);     // + one slot per query for k_merge_keys
     if (rc != ORBX_OK) return rc;
-    hipLaunchKernelGGL(k_best2_dense, dim3((cap + M_THREADS - 1) / M_THREADS, nbatch, S), dim3(M_THREADS), 0, s,
-                       d_q, d_nq, 0, d_t, d_nt, 0, (long long)cap * 32, (long long)cap * 32, cap, m->d_part);
+    if (m->dense_popcount)
+        hipLaunchKernelGGL(k_best2_dense, dim3((cap + M_THREADS - 1) / M_THREADS, nbatch, S), dim3(M_THREADS), 0, s,
+                           d_q, d_nq, 0, d_t, d_nt, 0, (long long)cap * 32, (long long)cap * 32, cap, m->d_part);
+    else if ((rc = orbm_launch_dense_mfma(m, d_q, d_nq, 0, d_t, d_nt, 0, (long long)cap * 32, (long long)cap * 32, cap, cap, nbatch, cap, S, m->d_part, s)) != ORBX_OK)
+        return rc;
     MHIPCHK(hipGetLastError());
     *S_out = S;
     return ORBX_OK;

@@ -684,6 +684,113 @@ extern "C" int orbm_search_by_projection_last(orbm_matcher *m, int n_last, const
     return ORBX_OK;
 }
 
+// ---- ORBmatcher::SearchByProjection(Frame &CurrentFrame, KeyFrame *pKF, const set<MapPoint*> &sAlreadyFound, th, ORBdist)
+// (src/ORBmatcher.cc:1472-1599), in three pieces so that a caller holding real MapPoint objects can keep calling its own
+// MapPoint::PredictScale between the projection and the search (mfMaxDistance is not reachable from outside the class) ----
+extern "C" int orbm_project_points(const float *Tcw, float fx, float fy, float cx, float cy, const float bounds[4],
+                                   const float *xw, int n, float *u, float *v, float *invzc, float *dist3d, uint8_t *in_image)
+{
+    if (!Tcw || !bounds || n < 0 || (n > 0 && (!xw || !u || !v || !in_image))) return mfail(ORBX_E_INVALID, "bad argument");
+    float Ow[3];                                    // Ow = -Rcw^T tcw (:1478), cv::Mat algebra as OpenCV's float GEMM
+    for (int k = 0; k < 3; k++)
+        Ow[k] = (float)((double)(-Tcw[k]) * Tcw[3] + (double)(-Tcw[4 + k]) * Tcw[7] + (double)(-Tcw[8 + k]) * Tcw[11]);
+    for (int i = 0; i < n; i++) {
+        const float *X = xw + 3 * (size_t)i;
+        const float xc = gemm_row(Tcw, 0, X), yc = gemm_row(Tcw, 1, X), zc = gemm_row(Tcw, 2, X);   // :1498
+        const float iz = (float)(1.0 / zc);                                                            // :1502
+        u[i] = fx * xc * iz + cx; v[i] = fy * yc * iz + cy;                                            // :1504-1505
+        in_image[i] = !(u[i] < bounds[0] || u[i] > bounds[1] || v[i] < bounds[2] || v[i] > bounds[3]); // :1507-1510
+        if (invzc) invzc[i] = iz;
+        if (dist3d) {                               // cv::norm(x3Dw - Ow) (:1513-1514): float difference, double accumulation
+            double nn = 0;
+            for (int k = 0; k < 3; k++) { const float po = X[k] - Ow[k]; nn += (double)po * (double)po; }
+            dist3d[i] = (float)sqrt(nn);
+        }
+    }
+    return ORBX_OK;
+}
+
+extern "C" int orbm_predict_scale(float mf_max_distance, float current_dist, float log_scale_factor, int n_levels)
+{
+    const float ratio = mf_max_distance / current_dist;                // src/MapPoint.cc:407
+    int nScale = (int)ceilf(logf(ratio) / log_scale_factor);          // :410 (log of a float: logf)
+    if (nScale < 0) nScale = 0;
+    else if (nScale >= n_levels) nScale = n_levels - 1;
+    return nScale;
+}
+
+extern "C" int orbm_search_by_projection_kf(orbm_matcher *m, int n_mp, const uint8_t *use, const float *proj_u, const float *proj_v,
+                                            const int32_t *pred_level, const uint8_t *mp_desc, const float *kf_angle,
+                                            const float *scale_factors, int nlevels, const orbx_keypoint *kps_cur, const uint8_t *desc_cur,
+                                            int n_cur, float th, int orb_dist, int check_orientation,
+                                            uint8_t *cur_has_point, int32_t *cur_match, int *nmatches)
+{
+    if (!m) return mfail(ORBX_E_INVALID, "NULL handle");
+    if (n_mp < 0 || n_cur < 0 || !scale_factors || nlevels < 1 || !nmatches ||
+        (n_mp > 0 && (!use || !proj_u || !proj_v || !pred_level || !mp_desc || (check_orientation && !kf_angle))) ||
+        (n_cur > 0 && (!kps_cur || !desc_cur || !cur_has_point || !cur_match)))
+        return mfail(ORBX_E_INVALID, "bad argument");
+    *nmatches = 0;
+    for (int i = 0; i < n_cur; i++) cur_match[i] = -1;
+    if (n_mp == 0 || n_cur == 0) return ORBX_OK;
+    if (!m->grid_ok || m->grid.n != n_cur) return mfail(ORBX_E_INVALID, "orbm_grid_build(current frame) has not been called");
+    std::vector<int> qi;
+    std::vector<float> x, y, r;
+    std::vector<int32_t> mn, mx;
+    for (int i = 0; i < n_mp; i++) {
+        if (!use[i]) continue;
+        const int lv = pred_level[i];
+        if (lv < 0 || lv >= nlevels) return mfail(ORBX_E_INVALID, "MapPoint %d predicted on level %d of %d", i, lv, nlevels);
+        qi.push_back(i); x.push_back(proj_u[i]); y.push_back(proj_v[i]); r.push_back(th * scale_factors[lv]);   // :1526
+        mn.push_back(lv - 1); mx.push_back(lv + 1);                                                              // :1528
+    }
+    const int nq = (int)qi.size();
+    if (nq == 0) return ORBX_OK;
+    if (nq > m->max_q) return mfail(ORBX_E_CAPACITY, "%d projected points, matcher sized for %d queries", nq, m->max_q);
+    std::vector<int32_t> off, idx, dist;
+    std::vector<uint8_t> qd((size_t)nq * 32);
+    for (int k = 0; k < nq; k++) memcpy(&qd[(size_t)k * 32], mp_desc + (size_t)qi[k] * 32, 32);
+    const int total = area_pairs(m, x.data(), y.data(), r.data(), mn.data(), mx.data(), nq, qd.data(), desc_cur, n_cur, off, idx, dist);
+    if (total < 0) return total;
+    // the sequential scan (:1538-1575): an assignment blocks the slot for every later MapPoint
+    std::vector<std::pair<int, int>> rot;
+    int32_t hist[ORBM_HISTO_LENGTH] = {0};
+    const float factor = 1.0f / ORBM_HISTO_LENGTH;
+    int nm = 0;
+    for (int k = 0; k < nq; k++) {
+        if (off[k + 1] == off[k]) continue;
+        int bestDist = 256, bestIdx2 = -1;
+        for (int c = off[k]; c < off[k + 1]; c++) {
+            const int i2 = idx[c];
+            if (cur_has_point[i2]) continue;
+            const int d = dist[c];
+            if (d < bestDist) { bestDist = d; bestIdx2 = i2; }
+        }
+        if (bestDist <= orb_dist && bestIdx2 >= 0) {
+            cur_has_point[bestIdx2] = 1;
+            cur_match[bestIdx2] = qi[k];
+            nm++;
+            if (check_orientation) {
+                float rot_ = kf_angle[qi[k]] - kps_cur[bestIdx2].angle;
+                if (rot_ < 0.0) rot_ += 360.0f;
+                int bin = (int)roundf(rot_ * factor);
+                if (bin == ORBM_HISTO_LENGTH) bin = 0;
+                if (bin < 0 || bin >= ORBM_HISTO_LENGTH) return mfail(ORBX_E_INVALID, "keypoint angle outside [0, 360)");
+                rot.emplace_back(bin, bestIdx2);
+                hist[bin]++;
+            }
+        }
+    }
+    if (check_orientation) {                         // :1577-1596
+        int32_t ind[3];
+        orbm_three_maxima(hist, ORBM_HISTO_LENGTH, ind);
+        for (const auto &e : rot)
+            if (e.first != ind[0] && e.first != ind[1] && e.first != ind[2]) { cur_has_point[e.second] = 0; cur_match[e.second] = -1; nm--; }
+    }
+    *nmatches = nm;
+    return ORBX_OK;
+}
+
 // ---- ORBmatcher::SearchByProjection(Frame&, const vector<MapPoint*>&, th) (src/ORBmatcher.cc:45-125) ----
 extern "C" int orbm_search_by_projection_map(orbm_matcher *m, int n_mp, const uint8_t *in_view, const float *proj_x, const float *proj_y,
                                              const float *proj_xr, const int32_t *pred_level, const float *view_cos, const uint8_t *mp_desc,

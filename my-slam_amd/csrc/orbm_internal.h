@@ -47,6 +47,7 @@ struct orbm_matcher {
     uint8_t *d_q = nullptr, *d_t = nullptr;
     int32_t *d_off = nullptr, *d_idx = nullptr, *d_out = nullptr;   // d_out: max(3*max_q, max_pairs) ints
     uint2 *d_part = nullptr; size_t part_elems = 0;                  // train-split partials (lazy)
+    int dense_popcount = 0;                                          // ORBM_DENSE=popcount: the VALU kernel instead of the matrix cores (A/B record)
     OrbmGrid grid = {};  bool grid_ok = false;                       // N1: Frame grid of the last orbm_grid_build
     float *d_qf = nullptr; int32_t *d_qi = nullptr; uint8_t *d_skip = nullptr;   // window-query staging (lazy)
     size_t qf_elems = 0;
@@ -62,6 +63,11 @@ int orbm_arena_begin(orbm_matcher *m);                                          
 int orbm_h2d(orbm_matcher *m, void *dev, const void *host, size_t bytes, hipStream_t s);   // staged host -> device copy
 int orbm_d2h(orbm_matcher *m, void *host, const void *dev, size_t bytes, hipStream_t s);   // staged; lands in host at orbm_sync()
 int orbm_sync(orbm_matcher *m, hipStream_t s);
+// orbm_mfma.hip: dense best / second-best partials on the matrix cores (same partial format as k_best2_dense)
+int orbm_mfma_splits(int nq_cap, int nt_cap, int nbatch);
+int orbm_launch_dense_mfma(orbm_matcher *m, const uint8_t *d_q, const int32_t *d_nq, int nq_fixed, const uint8_t *d_t, const int32_t *d_nt,
+                           int nt_fixed, long long qstride, long long tstride, int cap_q, int cap_t, int nbatch, int out_stride, int S,
+                           uint2 *part, hipStream_t s);
 // k_dist_csr (orbm.hip) for callers in other files: dist[c] of every CSR candidate, off has nq + 1 entries
 void orbm_launch_dist_csr(const uint8_t *d_q, int nq, const uint8_t *d_t, const int32_t *d_off, const int32_t *d_idx, int total,
                           int32_t *d_dist, hipStream_t s);

@@ -1,0 +1,229 @@
+// orbm_mfma.hip -- dense best / second-best DescriptorDistance (src/ORBmatcher.cc:1647-1663 inside the loops :201-226 and
+// siblings) on the gfx950 matrix cores.
+//
+// For 256-bit descriptors a, b:  hamming(a, b) = (256 - a'.b') / 2  with a'_k = +1 / -1 for bit k set / clear, so all
+// nq x nt distances of a frame pair are one integer GEMM.  v_mfma_i32_32x32x32_i8 is exact (i8 x i8 -> i32), so nothing about
+// the result changes; what changes is where the work runs: 16 popcount-VALU instructions per pair become 1/128 of an MFMA
+// plus two VALU instructions of selection.  The selection rules of the reference (strict '<': the lowest train index wins a
+// tie, a tie with the best becomes the second best) are folded into the product itself:
+//   operands are -+64 (so a'.b' arrives scaled by 4096) and the accumulator of output row i (train descriptor) starts at
+//   -(train index):      acc = 4096 * (256 - 2 * dist) - index
+//   a larger acc is a smaller distance and, among equal distances, a smaller index -- all accs of a query are distinct, so the
+//   two largest accs ARE the reference's best and second best (v_max_i32 + v_med3_i32 per element), and (dist, index) decode
+//   from the winner by shift and mask.  12 bits of index: the train range is walked in chunks of 4096 descriptors.
+// Layout: train descriptors are the A operand (output rows), queries the B operand (output columns): a lane's 16 accumulators
+// are 16 train rows of ONE query column (C/D map of the 32x32 shapes: col = lane & 31, row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5)),
+// so the running (best, second) of a query lives in two registers of its lane and only lanes l / l + 32 merge at the end.
+// A and B use the same lane -> k map (the instruction is symmetric in it), so any consistent choice gives the dot product.
+// The operand bytes are made from the descriptor bits inside the kernel (mf_expand16): nothing but the 32-byte descriptors is read.
+// The partial (best key, second key) pairs have the format of the popcount kernel (key = distance << 22 | train index), so
+// k_merge_best2 / k_merge_keys / k_accept_rot are shared.
+#include <algorithm>
+#include <cstdlib>
+#include "orbm_internal.h"
+
+typedef int v4i __attribute__((ext_vector_type(4)));
+typedef int v16i __attribute__((ext_vector_type(16)));
+
+#define MF_KEY_NONE ((256u << 22) | 0x3FFFFFu)
+#define MF_ACC_NONE (-(1 << 30))        // "no candidate yet"; a real acc is >= -(4096 * 256 + 4095)
+#define MF_ROW_NONE (-(1 << 29))        // start value of a row beyond the train count: stays below every real acc
+#define MF_QB 2                         // query blocks (32 queries each) per wave
+#define MF_CHUNK 4096                   // train descriptors per index chunk (12 bits)
+
+// 16 descriptor bits -> the 16 operand bytes of one lane and k-step: -64 for a set bit, +64 for a clear one (both operands are
+// made this way, and flipping the sign of both leaves every product as it is; this polarity is one instruction shorter).
+// Operand order: byte j of lane (r, h) in k-step s is bit 32 s + 16 h + j of descriptor r -- for the A and the B operand alike.
+__device__ __forceinline__ uint4 mf_expand16(uint32_t bits)
+{
+    uint32_t o[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        const uint32_t nib = (bits >> (4 * k)) & 0xFu;
+        const uint32_t spread = __umul24(nib, 0x00204081u) & 0x01010101u;     // bit i of the nibble -> bit 0 of byte i
+        o[k] = (spread << 7) | 0x40404040u;                                   // clear -> 0x40 (+64), set -> 0xC0 (-64)
+    }
+    return make_uint4(o[0], o[1], o[2], o[3]);
+}
+
+__device__ __forceinline__ uint32_t mf_med3u(uint32_t a, uint32_t b, uint32_t c) { return max(min(a, b), min(max(a, b), c)); }
+__device__ __forceinline__ int mf_med3i(int a, int b, int c) { return max(min(a, b), min(max(a, b), c)); }
+
+// (best acc, second acc) of a chunk -> the running (best key, second key)
+__device__ __forceinline__ void mf_fold(int &ba, int &sa, uint32_t &bk, uint32_t &sk, int c0)
+{
+#pragma unroll
+    for (int k = 0; k < 2; k++) {
+        const int x = k == 0 ? ba : sa;
+        if (x > -(1 << 22)) {
+            const int v = -x;                                    // index - 4096 * (256 - 2 dist)
+            const uint32_t idx = (uint32_t)v & (MF_CHUNK - 1);
+            const int two_d = 256 + (v >> 12);                   // arithmetic shift: (v - idx) / 4096 = -(256 - 2 dist)
+            const uint32_t key = ((uint32_t)(two_d >> 1) << 22) | (uint32_t)(c0 + (int)idx);
+            sk = mf_med3u(bk, sk, key);
+            bk = min(bk, key);
+        }
+    }
+    ba = MF_ACC_NONE; sa = MF_ACC_NONE;
+}
+
+// Workgroup = 4 waves x MF_QB query blocks against ONE SPLIT of the train descriptors of one frame pair; the split (<= MF_MAXT
+// tiles of 32 descriptors) sits in LDS whole, already expanded to operand bytes: every global load of the workgroup is issued up
+// front (one dword per thread and tile for the train side, the wave's 64 query descriptors as two 16-byte loads per lane), one
+// memory latency is paid once, and the MFMA phase runs from LDS and registers without another global wait or barrier.  The
+// expansion bits -> bytes is done here, on the fly (~24 VALU instructions per thread and tile against 16 MFMAs per wave and
+// tile): a pre-expanded copy in memory is 8x the bytes, and re-reading it per query block / per split made the kernel
+// memory-bound (163 MB per launch, 21 us with the MFMA pipe 23 % busy).  Three workgroups per CU: while one waits for its
+// loads the others compute.  The 1-D grid is ordered pair-major and dealt to the XCDs in contiguous eighths (placement only,
+// as in k_fast_cells), so the workgroups of a pair share an L2.
+#define MF_MAXT 6
+#ifdef MF_TRACE
+__device__ unsigned long long g_mf_trace[4 * 4096];
+extern "C" int orbm_debug_mf_trace(unsigned long long *out) { return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_mf_trace), sizeof(g_mf_trace)); }
+#define MF_STAMP(i) do { if (threadIdx.x == 0 && lb < 4096) g_mf_trace[4 * lb + (i)] = wall_clock64(); } while (0)
+#else
+#define MF_STAMP(i) do { } while (0)
+#endif
+__global__ __launch_bounds__(256, 3) void k_best2_mfma(const uint8_t *__restrict__ q, const int32_t *__restrict__ nqv, int nq_fixed,
+                                                       const uint8_t *__restrict__ t, const int32_t *__restrict__ ntv, int nt_fixed,
+                                                       long long qstride, long long tstride, int cap_q, int cap_t, int out_stride,
+                                                       uint2 *__restrict__ part, int nbx, int S, int nbatch, int total)
+{
+    __shared__ uint4 lds[MF_MAXT * 512];            // the split's train tiles as operand bytes (32 descriptors x 256 B = 8 KiB each)
+    const int lb = (int)(blockIdx.x & 7u) * (int)(gridDim.x >> 3) + (int)(blockIdx.x >> 3);
+    if (lb >= total) return;
+    MF_STAMP(0);
+    const int b = lb / (nbx * S), rem = lb - b * (nbx * S), bz = rem / nbx, bx = rem - bz * nbx;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int qb0 = (bx * 4 + wave) * MF_QB;
+    const uint8_t *Q = q + (long long)b * qstride, *T = t + (long long)b * tstride;
+    // All loads first, and none of them waits for another: the descriptor loads go by the CAPACITY of the arrays (rows up to
+    // cap_q / cap_t are allocated, whatever the counts say) while the counts themselves are still on their way; what lies beyond
+    // the counts is masked afterwards.  (Counts first, then addresses, then data was two dependent round trips to memory,
+    // ~2 us of a workgroup's ~8.)  The split geometry comes from cap_t for the same reason.
+    const int ttiles_cap = (cap_t + 31) >> 5, per = min((ttiles_cap + S - 1) / S, MF_MAXT);   // the host picks S with ceil(tiles / S) <= MF_MAXT
+    const int t0 = bz * per, t1c = min(ttiles_cap, t0 + per);
+    // Train: thread (r = tid & 31, s = tid >> 5) takes word s of descriptor r of every tile of the split.
+    const int tr = tid & 31, ts = tid >> 5;
+    uint32_t tw[MF_MAXT];
+#pragma unroll
+    for (int j = 0; j < MF_MAXT; j++) {
+        const int row = (t0 + j) * 32 + tr;
+        tw[j] = (t0 + j < t1c && row < cap_t) ? *reinterpret_cast<const uint32_t *>(T + (long long)row * 32 + 4 * ts) : 0u;
+    }
+    // Queries: lane (r, h) of a wave takes descriptor r of each of its MF_QB blocks whole (two 16-byte loads)
+    const int qr = lane & 31, qh = lane >> 5;
+    uint4 qw[MF_QB][2];
+#pragma unroll
+    for (int u = 0; u < MF_QB; u++) {
+        const int row = (qb0 + u) * 32 + qr;
+        qw[u][0] = qw[u][1] = make_uint4(0, 0, 0, 0);
+        if (row < cap_q) {
+            const uint4 *p = reinterpret_cast<const uint4 *>(Q + (long long)row * 32);
+            qw[u][0] = p[0]; qw[u][1] = p[1];
+        }
+    }
+    const int nq = nqv ? nqv[b] : nq_fixed, nt = ntv ? ntv[b] : nt_fixed;
+    const int qblocks = (nq + 31) >> 5;
+    if (bx * 4 * MF_QB >= qblocks) return;                                   // nothing for this workgroup (uniform)
+    const bool active = qb0 < qblocks;                                       // wave-uniform; idle waves still help staging
+    const int t1 = min((nt + 31) >> 5, t1c);
+    // expand: train words -> LDS (both lane halves of the word's k-step), query words -> the B operand registers
+#pragma unroll
+    for (int j = 0; j < MF_MAXT; j++)
+        if (t0 + j < t1) {
+            const bool valid = (t0 + j) * 32 + tr < nt;     // rows beyond the count: zero operand bytes (they never win: MF_ROW_NONE)
+            lds[j * 512 + ts * 64 + tr] = valid ? mf_expand16(tw[j] & 0xFFFFu) : make_uint4(0, 0, 0, 0);
+            lds[j * 512 + ts * 64 + 32 + tr] = valid ? mf_expand16(tw[j] >> 16) : make_uint4(0, 0, 0, 0);
+        }
+    v4i bq[MF_QB][8];
+#pragma unroll
+    for (int u = 0; u < MF_QB; u++) {
+        const uint32_t w8[8] = {qw[u][0].x, qw[u][0].y, qw[u][0].z, qw[u][0].w, qw[u][1].x, qw[u][1].y, qw[u][1].z, qw[u][1].w};
+#pragma unroll
+        for (int s = 0; s < 8; s++) bq[u][s] = __builtin_bit_cast(v4i, mf_expand16((w8[s] >> (16 * qh)) & 0xFFFFu));
+    }
+    __syncthreads();
+    MF_STAMP(1);
+    if (!active) return;
+
+    int ba[MF_QB], sa[MF_QB];
+    uint32_t bk[MF_QB], sk[MF_QB];
+#pragma unroll
+    for (int u = 0; u < MF_QB; u++) { ba[u] = sa[u] = MF_ACC_NONE; bk[u] = sk[u] = MF_KEY_NONE; }
+    const int h4 = 4 * (lane >> 5);
+    int c0 = (t0 * 32) & ~(MF_CHUNK - 1);
+    for (int tt = t0; tt < t1; tt++) {
+        const int base = tt * 32;
+        if ((base & ~(MF_CHUNK - 1)) != c0) {       // next index chunk: bank the finished one
+#pragma unroll
+            for (int u = 0; u < MF_QB; u++) mf_fold(ba[u], sa[u], bk[u], sk[u], c0);
+            c0 = base & ~(MF_CHUNK - 1);
+        }
+        v16i init;
+        const int top = c0 - base - h4;             // -(index of row 0 of this lane's half) relative to the chunk
+#pragma unroll
+        for (int r = 0; r < 16; r++) init[r] = top - ((r & 3) + 8 * (r >> 2));
+        if (base + 32 > nt) {                       // last, partial tile: rows beyond the train count never win
+#pragma unroll
+            for (int r = 0; r < 16; r++)
+                if (base + h4 + (r & 3) + 8 * (r >> 2) >= nt) init[r] = MF_ROW_NONE;
+        }
+        const uint4 *A = &lds[(tt - t0) * 512];
+        v16i acc[MF_QB];
+        const v4i a0 = __builtin_bit_cast(v4i, A[lane]);
+#pragma unroll
+        for (int u = 0; u < MF_QB; u++) acc[u] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a0, bq[u][0], init, 0, 0, 0);
+#pragma unroll
+        for (int s = 1; s < 8; s++) {
+            const v4i a = __builtin_bit_cast(v4i, A[s * 64 + lane]);
+#pragma unroll
+            for (int u = 0; u < MF_QB; u++) acc[u] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a, bq[u][s], acc[u], 0, 0, 0);
+        }
+#pragma unroll
+        for (int u = 0; u < MF_QB; u++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) {
+                const int x = acc[u][r];
+                sa[u] = mf_med3i(ba[u], sa[u], x);               // second largest of {ba >= sa, x}
+                ba[u] = max(ba[u], x);
+            }
+    }
+#pragma unroll
+    for (int u = 0; u < MF_QB; u++) {
+        mf_fold(ba[u], sa[u], bk[u], sk[u], c0);
+        // lanes l and l + 32 hold the two halves of the rows of one query column
+        const uint32_t obk = __shfl_xor(bk[u], 32), osk = __shfl_xor(sk[u], 32);
+        uint32_t k1 = bk[u], k2 = sk[u];
+        k2 = mf_med3u(k1, k2, obk); k1 = min(k1, obk);
+        k2 = mf_med3u(k1, k2, osk); k1 = min(k1, osk);
+        const int qi = (qb0 + u) * 32 + (lane & 31);
+        if (lane < 32 && qi < nq) part[((long long)bz * nbatch + b) * out_stride + qi] = make_uint2(k1, k2);
+    }
+    MF_STAMP(2);
+}
+
+int orbm_mfma_splits(int nq_cap, int nt_cap, int nbatch)
+{
+    // a split is at most MF_MAXT train tiles (it has to fit the workgroup's LDS); beyond that, enough workgroups for three per CU
+    const int ttiles = std::max((nt_cap + 31) >> 5, 1);
+    int S = (ttiles + MF_MAXT - 1) / MF_MAXT;
+    const long long wgs = (long long)nbatch * ((((nq_cap + 31) >> 5) + 4 * MF_QB - 1) / (4 * MF_QB));
+    while ((long long)S * wgs < 768 && S < ttiles) S++;
+    if (const char *e = getenv("ORBM_MFMA_SPLITS")) S = std::max(atoi(e), (ttiles + MF_MAXT - 1) / MF_MAXT);   // tuning switch
+    return std::min(S, ttiles);
+}
+
+// Partials of nbatch dense pairs -> part[S][nbatch][out_stride]; counts per pair from d_nq / d_nt (device) or the fixed values.
+int orbm_launch_dense_mfma(orbm_matcher *m, const uint8_t *d_q, const int32_t *d_nq, int nq_fixed, const uint8_t *d_t, const int32_t *d_nt,
+                           int nt_fixed, long long qstride, long long tstride, int cap_q, int cap_t, int nbatch, int out_stride, int S,
+                           uint2 *part, hipStream_t s)
+{
+    (void)m;
+    const int qtiles = (cap_q + 31) >> 5;
+    const int nbx = (qtiles + 4 * MF_QB - 1) / (4 * MF_QB), total = nbx * S * nbatch;
+    hipLaunchKernelGGL(k_best2_mfma, dim3((unsigned)((total + 7) & ~7)), dim3(256), 0, s,
+                       d_q, d_nq, nq_fixed, d_t, d_nt, nt_fixed, qstride, tstride, cap_q, cap_t, out_stride, part, nbx, S, nbatch, total);
+    MHIPCHK(hipGetLastError());
+    return ORBX_OK;
+}

@@ -2,16 +2,86 @@
 // The arithmetic here restates the reference constructor and OpenCV's resize planning on the host
 // (citations: src/ORBextractor.cc of WChen09/My-SLAM); all pixel work is in the per-stage kernel files (orbx_pyramid/fast/octree/describe.hip).
 #include <cfloat>
+#include <chrono>
 #include <cstdarg>
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <atomic>
+#include <condition_variable>
+#include <functional>
+#include <mutex>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "orbx_internal.h"
+
+// A few helper threads for the host side of orbx_extract_batch: repacking 64 frames into the pinned staging buffer is ~20 MB
+// of memcpy, which one core moves slower than PCIe gen5 does.  Workers keep polling for ~0.3 ms after a job (the chunks of one
+// batch arrive back to back), then sleep on a condition variable.
+class StagePool {
+public:
+    explicit StagePool(int nthreads)
+    {
+        for (int i = 0; i < nthreads; i++) th_.emplace_back([this] { worker(); });
+    }
+    ~StagePool()
+    {
+        { std::lock_guard<std::mutex> lk(mu_); quit_ = true; gen_.fetch_add(1); }
+        cv_.notify_all();
+        for (auto &t : th_) t.join();
+    }
+    // fn(i) for i in [0, n), spread over the workers and the calling thread; returns when all are done
+    void parallel_for(int n, const std::function<void(int)> &fn)
+    {
+        if (n <= 0) return;
+        if (th_.empty() || n == 1) { for (int i = 0; i < n; i++) fn(i); return; }
+        fn_ = &fn; n_ = n; next_.store(0); left_.store(n);
+        { std::lock_guard<std::mutex> lk(mu_); gen_.fetch_add(1); }
+        cv_.notify_all();
+        drain();
+        while (left_.load(std::memory_order_acquire) > 0) std::this_thread::yield();
+    }
+private:
+    void drain()
+    {
+        for (;;) {
+            const int i = next_.fetch_add(1);
+            if (i >= n_) return;
+            (*fn_)(i);
+            left_.fetch_sub(1, std::memory_order_release);
+        }
+    }
+    void worker()
+    {
+        unsigned long long seen = 0;
+        for (;;) {
+            const auto t0 = std::chrono::steady_clock::now();
+            while (gen_.load(std::memory_order_acquire) == seen) {        // poll first, sleep later
+                if (std::chrono::steady_clock::now() - t0 > std::chrono::microseconds(300)) {
+                    std::unique_lock<std::mutex> lk(mu_);
+                    cv_.wait(lk, [&] { return gen_.load() != seen; });
+                    break;
+                }
+                std::this_thread::yield();
+            }
+            seen = gen_.load(std::memory_order_acquire);
+            if (quit_) return;
+            drain();
+        }
+    }
+    std::vector<std::thread> th_;
+    std::mutex mu_;
+    std::condition_variable cv_;
+    std::atomic<unsigned long long> gen_{0};
+    std::atomic<int> next_{0}, left_{0};
+    const std::function<void(int)> *fn_ = nullptr;
+    int n_ = 0;
+    bool quit_ = false;
+};
 
 static thread_local std::string g_err;
 static int fail(int code, const char *fmt, ...)
@@ -67,6 +137,10 @@ struct orbx_extractor {
     int inflight = 0, inflight_frames = 0;      // orbx_extract_begin / orbx_extract_end
     // orbx_extract_begin replays one HIP graph per shape (upload, ~10 kernels, download) instead of ~12 launches
     hipGraphExec_t graph_exec = nullptr; int graph_w = 0, graph_h = 0, graph_seen_w = 0, graph_seen_h = 0; bool graph_off = false;
+    // orbx_extract_batch in chunks: staging threads, two streams, one HIP graph per chunk (kernels + download) per shape
+    StagePool *pool = nullptr; int batch_chunk = 16;
+    std::vector<hipGraphExec_t> bgraph; int bg_w = 0, bg_h = 0, bg_n = 0, bg_chunk = 0; bool bg_off = false;
+    std::vector<hipEvent_t> ev_up, ev_done;
     int profiling = 0; hipEvent_t ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr}; float stage_ms[4] = {0, 0, 0, 0};
     // profiling == 2: the stage events of the last ORBX_PROF_RING calls are recorded and never waited for by the library
     hipEvent_t evr[ORBX_PROF_RING][5] = {}; long long ring_calls = 0;
@@ -205,6 +279,10 @@ static void free_all(orbx_extractor *h)
     hipFree(h->d_out);
     hipHostFree(h->h_in); hipHostFree(h->h_out);
     if (h->graph_exec) hipGraphExecDestroy(h->graph_exec);
+    for (auto &g : h->bgraph) if (g) hipGraphExecDestroy(g);
+    delete h->pool;
+    for (auto &e : h->ev_up) if (e) hipEventDestroy(e);
+    for (auto &e : h->ev_done) if (e) hipEventDestroy(e);
     for (auto &e : h->ev) if (e) hipEventDestroy(e);
     for (auto &set : h->evr) for (auto &e : set) if (e) hipEventDestroy(e);
     for (auto &e : h->ev_join) if (e) hipEventDestroy(e);
@@ -308,6 +386,9 @@ extern "C" int orbx_set_option(orbx_extractor *h, int option, int value)
 {
     if (!h) return fail(ORBX_E_INVALID, "NULL handle");
     if (h->graph_exec) { (void)hipGraphExecDestroy(h->graph_exec); h->graph_exec = nullptr; h->graph_w = h->graph_h = 0; }   // options are baked into the graph
+    for (auto &g : h->bgraph) if (g) (void)hipGraphExecDestroy(g);
+    h->bgraph.clear(); h->bg_w = h->bg_h = h->bg_n = 0;
+    if (option == ORBX_OPT_BATCH_CHUNK && value >= 0 && value <= 4096) { h->batch_chunk = value; return ORBX_OK; }
     if (option == ORBX_OPT_BLUR_ROUNDING && (value == 0 || value == 1)) { h->blur_mode = value; h->plan.blur_mode = value; return ORBX_OK; }
     if (option == ORBX_OPT_SUBBATCHES && value >= 1 && value <= ORBX_MAX_SUB) { h->nsub = value; return ORBX_OK; }
     if (option == ORBX_OPT_OVERLAP_PYRAMID && (value == 0 || value == 1)) { h->overlap_pyr = value; return ORBX_OK; }
@@ -418,7 +499,7 @@ static int ensure_plan(orbx_extractor *h, int W, int H)
 // enqueue the whole pipeline for `nframes` frames already resident in HBM
 static int enqueue(orbx_extractor *h, const uint8_t *d_images, int nframes, int W, int H, int row_stride,
                    long long frame_stride, orbx_keypoint *d_kps, uint8_t *d_desc, int32_t *d_counts,
-                   int32_t *d_status, hipStream_t s)
+                   int32_t *d_status, hipStream_t s, int work_frame0 = 0)   // work_frame0: first frame slot of the workspace / pyramid
 {
     int rc = ensure_plan(h, W, H);
     if (rc != ORBX_OK) return rc;
@@ -438,7 +519,7 @@ static int enqueue(orbx_extractor *h, const uint8_t *d_images, int nframes, int 
     }
     struct DirtyGuard { orbx_extractor *h; bool ok = false; ~DirtyGuard() { if (!ok) h->need_clear = true; } } guard{h};
     const uint8_t *src_end = nullptr;   // level 0 in caller memory has no slack behind its last byte
-    if (d_images != h->d_input)
+    if (d_images < h->d_input || d_images >= h->d_input + (size_t)h->max_batch * h->in_frame)   // the handle's own input block has slack
         src_end = d_images + (long long)(nframes - 1) * frame_stride + (long long)(H - 1) * row_stride + W;
 
     // Sub-batches on separate streams: the quadtree and the small pyramid levels are latency-bound
@@ -454,8 +535,9 @@ static int enqueue(orbx_extractor *h, const uint8_t *d_images, int nframes, int 
         st[i] = i == 0 ? s : h->aux[i - 1];
         sp[i] = P;
         sw[i] = h->work;
-        const long long o = f0[i];
-        for (int l = 0; l < h->nlevels; l++) sp[i].lv[l].base = P.lv[l].base + o * P.lv[l].frame_stride;
+        const long long o = (long long)work_frame0 + f0[i];
+        sp[i].lv[0].base = P.lv[0].base + (long long)f0[i] * P.lv[0].frame_stride;      // d_images is this call's first frame already
+        for (int l = 1; l < h->nlevels; l++) sp[i].lv[l].base = P.lv[l].base + o * P.lv[l].frame_stride;
         sw[i].cand += o * P.cand_frame; sw[i].owner += o * P.cand_frame; sw[i].arena += o * P.arena_frame;
         sw[i].sel += o * P.list_frame; sw[i].nk += o * h->nlevels; sw[i].ncand += o * h->nlevels; sw[i].errflags += o;
         sw[i].cand_count += o * h->nlevels * ORBX_CNT_STRIDE;
@@ -532,30 +614,52 @@ extern "C" int orbx_extract_batch_device(orbx_extractor *h, const uint8_t *d_ima
     return ORBX_OK;
 }
 
-extern "C" int orbx_extract_batch(orbx_extractor *h, const uint8_t *images, int nframes, int width, int height,
-                                  int row_stride, size_t frame_stride, orbx_keypoint *keypoints,
-                                  uint8_t *descriptors, int cap, int *counts)
+// repack frames [k0, k1) into the pinned staging buffer with the aligned pitch (a pitched hipMemcpy2D of a 1241-byte-wide image
+// costs ~3 ms; this and ONE contiguous copy cost ~0.1 ms); rows are dealt to the staging threads in blocks
+static void stage_frames(orbx_extractor *h, const uint8_t *images, int k0, int k1, int width, int height, int row_stride, size_t frame_stride)
 {
-    if (!h) return fail(ORBX_E_INVALID, "NULL handle");
-    if (!counts) return fail(ORBX_E_INVALID, "counts is NULL");
-    for (int k = 0; k < std::max(nframes, 0); k++) counts[k] = 0;
-    if (h->inflight) return fail(ORBX_E_INVALID, "an orbx_extract_begin call is in flight on this handle");
-    if (!images || width <= 0 || height <= 0 || nframes <= 0) return ORBX_OK;   // :1048 empty image: silent return
-    if (!keypoints || !descriptors) return fail(ORBX_E_INVALID, "NULL output buffer");
-    if (nframes > h->max_batch) return fail(ORBX_E_INVALID, "nframes=%d (max_batch=%d)", nframes, h->max_batch);
-    if (row_stride < width) return fail(ORBX_E_INVALID, "row_stride %d < width %d", row_stride, width);
-    if (width > h->max_w || height > h->max_h) return fail(ORBX_E_SHAPE, "frame %dx%d exceeds the handle's max %dx%d", width, height, h->max_w, h->max_h);
-    HIPCHK(hipSetDevice(h->device));
-    hipStream_t s = h->stream;
-    const int ocap = h->max_plan.out_cap;
-    // repack into the pinned staging buffer with the aligned pitch, then ONE contiguous H2D copy
-    // (a pitched hipMemcpy2D of a 1241-byte-wide image costs ~3 ms; this costs ~0.1 ms)
-    for (int k = 0; k < nframes; k++) {
+    const int RB = 64, nblk = (height + RB - 1) / RB;
+    auto unit = [&](int u) {
+        const int k = k0 + u / nblk, y0 = (u % nblk) * RB, y1 = std::min(height, y0 + RB);
         uint8_t *dst = h->h_in + (size_t)k * h->in_frame;
         const uint8_t *src = images + (size_t)k * frame_stride;
-        if (row_stride == h->in_stride) memcpy(dst, src, (size_t)row_stride * height);
-        else for (int y = 0; y < height; y++) memcpy(dst + (size_t)y * h->in_stride, src + (size_t)y * row_stride, (size_t)width);
+        if (row_stride == h->in_stride) memcpy(dst + (size_t)y0 * row_stride, src + (size_t)y0 * row_stride, (size_t)row_stride * (y1 - y0 - 1) + width);
+        else for (int y = y0; y < y1; y++) memcpy(dst + (size_t)y * h->in_stride, src + (size_t)y * row_stride, (size_t)width);
+    };
+    const int n = (k1 - k0) * nblk;
+    if (h->pool) h->pool->parallel_for(n, unit);
+    else for (int u = 0; u < n; u++) unit(u);
+}
+
+static int deliver_batch(orbx_extractor *h, int k0, int k1, orbx_keypoint *keypoints, uint8_t *descriptors, int cap, int *counts)
+{
+    const int ocap = h->max_plan.out_cap;
+    for (int k = k0; k < k1; k++) {
+        if (h->h_status[k] != ORBX_OK)
+            return fail(h->h_status[k], "frame %d: device status %d (%s)", k, h->h_status[k],
+                        h->h_status[k] == ORBX_E_CAND_OVERFLOW ? "FAST candidate buffer overflow" :
+                        h->h_status[k] == ORBX_E_TREE_OVERFLOW ? "quadtree arena overflow" : "capacity");
+        if (h->h_counts[k] > cap) return fail(ORBX_E_CAPACITY, "frame %d produced %d keypoints, caller capacity %d (use orbx_capacity())", k, h->h_counts[k], cap);
     }
+    auto unit = [&](int u) {
+        const int k = k0 + u, n = h->h_counts[k];
+        memcpy(keypoints + (size_t)k * cap, h->h_kps + (size_t)k * ocap, sizeof(orbx_keypoint) * n);
+        memcpy(descriptors + (size_t)k * cap * 32, h->h_desc + (size_t)k * ocap * 32, (size_t)32 * n);
+        counts[k] = n;
+    };
+    if (h->pool && k1 - k0 >= 8) h->pool->parallel_for(k1 - k0, unit);
+    else for (int u = 0; u < k1 - k0; u++) unit(u);
+    return ORBX_OK;
+}
+
+// The whole batch in one piece: upload, kernels, download, strictly one after the other (first call of a shape, profiling,
+// small batches).
+static int extract_batch_simple(orbx_extractor *h, const uint8_t *images, int nframes, int width, int height, int row_stride,
+                                size_t frame_stride, orbx_keypoint *keypoints, uint8_t *descriptors, int cap, int *counts)
+{
+    hipStream_t s = h->stream;
+    const int ocap = h->max_plan.out_cap;
+    stage_frames(h, images, 0, nframes, width, height, row_stride, frame_stride);
     HIPCHK(hipMemcpyAsync(h->d_input, h->h_in, (size_t)(nframes - 1) * h->in_frame + (size_t)h->in_stride * height,
                           hipMemcpyHostToDevice, s));
     int rc = enqueue(h, h->d_input, nframes, width, height, h->in_stride, (long long)h->in_frame, h->d_kps, h->d_desc,
@@ -571,18 +675,130 @@ extern "C" int orbx_extract_batch(orbx_extractor *h, const uint8_t *images, int 
     HIPCHK(hipStreamSynchronize(s));
     rc = finish_profile(h);
     if (rc != ORBX_OK) return rc;
-    for (int k = 0; k < nframes; k++) {
-        if (h->h_status[k] != ORBX_OK)
-            return fail(h->h_status[k], "frame %d: device status %d (%s)", k, h->h_status[k],
-                        h->h_status[k] == ORBX_E_CAND_OVERFLOW ? "FAST candidate buffer overflow" :
-                        h->h_status[k] == ORBX_E_TREE_OVERFLOW ? "quadtree arena overflow" : "capacity");
-        const int n = h->h_counts[k];
-        if (n > cap) return fail(ORBX_E_CAPACITY, "frame %d produced %d keypoints, caller capacity %d (use orbx_capacity())", k, n, cap);
-        memcpy(keypoints + (size_t)k * cap, h->h_kps + (size_t)k * ocap, sizeof(orbx_keypoint) * n);
-        memcpy(descriptors + (size_t)k * cap * 32, h->h_desc + (size_t)k * ocap * 32, (size_t)32 * n);
-        counts[k] = n;
-    }
+    return deliver_batch(h, 0, nframes, keypoints, descriptors, cap, counts);
+}
+
+// kernels + download of frames [k0, k1) of the handle's own input block, on stream s
+static int enqueue_chunk(orbx_extractor *h, int k0, int k1, int width, int height, hipStream_t s)
+{
+    const int ocap = h->max_plan.out_cap, nf = k1 - k0;
+    int rc = enqueue(h, h->d_input + (size_t)k0 * h->in_frame, nf, width, height, h->in_stride, (long long)h->in_frame,
+                     h->d_kps + (size_t)k0 * ocap, h->d_desc + (size_t)k0 * ocap * 32, h->d_counts + k0, h->d_status + k0, s, k0);
+    if (rc != ORBX_OK) return rc;
+    HIPCHK(hipMemcpyAsync(h->h_counts + k0, h->d_counts + k0, sizeof(int32_t) * nf, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipMemcpyAsync(h->h_status + k0, h->d_status + k0, sizeof(int32_t) * nf, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipMemcpyAsync(h->h_kps + (size_t)k0 * ocap, h->d_kps + (size_t)k0 * ocap, sizeof(orbx_keypoint) * (size_t)ocap * nf, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipMemcpyAsync(h->h_desc + (size_t)k0 * ocap * 32, h->d_desc + (size_t)k0 * ocap * 32, (size_t)32 * ocap * nf, hipMemcpyDeviceToHost, s));
     return ORBX_OK;
+}
+
+extern "C" int orbx_extract_batch(orbx_extractor *h, const uint8_t *images, int nframes, int width, int height,
+                                  int row_stride, size_t frame_stride, orbx_keypoint *keypoints,
+                                  uint8_t *descriptors, int cap, int *counts)
+{
+    if (!h) return fail(ORBX_E_INVALID, "NULL handle");
+    if (!counts) return fail(ORBX_E_INVALID, "counts is NULL");
+    for (int k = 0; k < std::max(nframes, 0); k++) counts[k] = 0;
+    if (h->inflight) return fail(ORBX_E_INVALID, "an orbx_extract_begin call is in flight on this handle");
+    if (!images || width <= 0 || height <= 0 || nframes <= 0) return ORBX_OK;   // :1048 empty image: silent return
+    if (!keypoints || !descriptors) return fail(ORBX_E_INVALID, "NULL output buffer");
+    if (nframes > h->max_batch) return fail(ORBX_E_INVALID, "nframes=%d (max_batch=%d)", nframes, h->max_batch);
+    if (row_stride < width) return fail(ORBX_E_INVALID, "row_stride %d < width %d", row_stride, width);
+    if (width > h->max_w || height > h->max_h) return fail(ORBX_E_SHAPE, "frame %dx%d exceeds the handle's max %dx%d", width, height, h->max_w, h->max_h);
+    HIPCHK(hipSetDevice(h->device));
+    if (!h->pool && nframes >= 8) {                         // staging threads: up to 6, leaving cores to the caller
+        const unsigned hc = std::thread::hardware_concurrency();
+        h->pool = new StagePool((int)std::min<unsigned>(6u, hc > 2 ? hc / 2 - 1 : 0u));
+    }
+    // Chunked pipeline ("host-buffer batches"): while chunk c is uploaded and extracted, chunk c + 1 is repacked by the
+    // staging threads; chunks alternate between two streams, so the upload of one runs under the kernels of the other, and each
+    // chunk's ten kernels + four downloads are ONE graph launch (a launch is ~5 us of host time, a chunk would be ~70).  Every
+    // chunk works in its own slice of the workspace.  The first call of a shape, profiling runs and small batches take the
+    // plain path.
+    const int chunk = h->batch_chunk;
+    const bool chunked = chunk > 0 && nframes >= 2 * chunk && h->profiling == 0 && !h->need_clear && width == h->cur_w && height == h->cur_h;
+    if (!chunked) return extract_batch_simple(h, images, nframes, width, height, row_stride, frame_stride, keypoints, descriptors, cap, counts);
+
+    // chunk boundaries: a half-size first chunk (the pipeline starts sooner) and a half-size last one (the tail that nothing hides
+    // is shorter) around full-size ones
+    std::vector<int> cut(1, 0);
+    if (nframes >= 3 * chunk && chunk >= 2) {
+        cut.push_back(chunk / 2);
+        while (nframes - cut.back() > chunk + chunk / 2) cut.push_back(cut.back() + chunk);
+        if (nframes - cut.back() > chunk / 2) cut.push_back(nframes - chunk / 2);
+    } else {
+        while (nframes - cut.back() > chunk) cut.push_back(cut.back() + chunk);
+    }
+    cut.push_back(nframes);
+    const int nch = (int)cut.size() - 1;
+    hipStream_t st[2] = {h->stream, h->aux[0]};
+    const bool have_graphs = !h->bg_off && h->bg_w == width && h->bg_h == height && h->bg_n == nframes && h->bg_chunk == chunk && (int)h->bgraph.size() == nch;
+    if (!have_graphs && !h->bg_off) {                       // (re)build the per-chunk graphs for this shape
+        for (auto &g : h->bgraph) if (g) (void)hipGraphExecDestroy(g);
+        h->bgraph.assign(nch, nullptr);
+        bool ok = true;
+        for (int c = 0; c < nch && ok; c++) {
+            hipStream_t s = st[c & 1];
+            ok = hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal) == hipSuccess;
+            if (!ok) break;
+            const int rc = enqueue_chunk(h, cut[c], cut[c + 1], width, height, s);
+            hipGraph_t g = nullptr;
+            const hipError_t e = hipStreamEndCapture(s, &g);
+            ok = rc == ORBX_OK && e == hipSuccess && g && hipGraphInstantiate(&h->bgraph[c], g, nullptr, nullptr, 0) == hipSuccess;
+            if (g) (void)hipGraphDestroy(g);
+        }
+        if (ok) { h->bg_w = width; h->bg_h = height; h->bg_n = nframes; h->bg_chunk = chunk; }
+        else {
+            (void)hipGetLastError();
+            for (auto &g : h->bgraph) if (g) (void)hipGraphExecDestroy(g);
+            h->bgraph.clear(); h->bg_off = true; h->bg_w = h->bg_h = h->bg_n = 0;
+        }
+    }
+    const bool graphs = !h->bg_off && (int)h->bgraph.size() == nch;
+    static const bool trace = getenv("ORBX_BATCH_TRACE") != nullptr;      // host-side time split of a call, to stderr
+    auto now = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    // uploads go back to back on a stream of their own (on a chunk's compute stream the upload of chunk c + 2 would wait for
+    // chunk c's kernels and downloads); each chunk's kernels wait for its own upload only
+    hipStream_t up = h->aux[1];
+    while ((int)h->ev_up.size() < nch) {
+        hipEvent_t a = nullptr, b = nullptr;
+        HIPCHK(hipEventCreateWithFlags(&a, hipEventDisableTiming)); h->ev_up.push_back(a);
+        HIPCHK(hipEventCreateWithFlags(&b, hipEventDisableTiming)); h->ev_done.push_back(b);
+    }
+    double t_stage = 0, t_launch = 0;
+    const double t_begin = trace ? now() : 0;
+    for (int c = 0; c < nch; c++) {
+        const int k0 = cut[c], k1 = cut[c + 1];
+        hipStream_t s = st[c & 1];
+        const double ta = trace ? now() : 0;
+        stage_frames(h, images, k0, k1, width, height, row_stride, frame_stride);
+        const double tb = trace ? now() : 0;
+        HIPCHK(hipMemcpyAsync(h->d_input + (size_t)k0 * h->in_frame, h->h_in + (size_t)k0 * h->in_frame,
+                              (size_t)(k1 - k0 - 1) * h->in_frame + (size_t)h->in_stride * height, hipMemcpyHostToDevice, up));
+        HIPCHK(hipEventRecord(h->ev_up[c], up));
+        HIPCHK(hipStreamWaitEvent(s, h->ev_up[c], 0));
+        if (graphs) HIPCHK(hipGraphLaunch(h->bgraph[c], s));
+        else { int rc = enqueue_chunk(h, k0, k1, width, height, s); if (rc != ORBX_OK) return rc; }
+        HIPCHK(hipEventRecord(h->ev_done[c], s));
+        if (trace) { t_stage += tb - ta; t_launch += now() - tb; }
+    }
+    const double t_issued = trace ? now() : 0;
+    // hand the chunks over as they finish: the copy-out of chunk c runs under the kernels of the chunks behind it
+    double t_wait = 0;
+    int rcd = ORBX_OK;
+    for (int c = 0; c < nch; c++) {
+        const int k0 = cut[c], k1 = cut[c + 1];
+        const double tw = trace ? now() : 0;
+        HIPCHK(hipEventSynchronize(h->ev_done[c]));
+        if (trace) t_wait += now() - tw;
+        if (rcd == ORBX_OK) rcd = deliver_batch(h, k0, k1, keypoints, descriptors, cap, counts);
+    }
+    HIPCHK(hipStreamSynchronize(up));
+    h->last_input = h->d_input; h->last_in_stride = h->in_stride; h->last_in_frame = (long long)h->in_frame; h->last_batch = nframes;
+    if (trace)
+        fprintf(stderr, "orbx_extract_batch %d frames, %d chunks%s: stage %.3f ms, launch %.3f, wait %.3f, deliver %.3f, total %.3f\n", nframes, nch,
+                graphs ? " (graphs)" : "", t_stage, t_launch, t_wait, now() - t_issued - t_wait, now() - t_begin);
+    return rcd;
 }
 
 extern "C" int orbx_extract_begin(orbx_extractor *h, const uint8_t *image, int width, int height, int stride)

@@ -3,12 +3,18 @@
 // src/Frame.cc:247-253 (ExtractORB) and src/Tracking.cc:121-127 compile unchanged; the work is done
 // by liborbx.so (hand-written HIP for gfx950) through the C ABI of include/orbx.h.
 //
+// Written against OpenCV 3.1.0's API (image.getMat(), descriptors.create() + getMat(), the CV_8U / CV_8UC1
+// macros); on a host without OpenCV, orbx_cv_compat.h models those same calls so that this exact code is
+// what the repo's tests compile.
+//
 // Differences a maintainer should know:
 //   * mvImagePyramid is filled lazily by FetchImagePyramid() (a D2H copy per level); only
 //     Frame::ComputeStereoMatches reads it (src/Frame.cc:473,563,580).
-//   * Failures of the GPU layer produce an empty result, the reference's only failure mode
-//     (src/ORBextractor.cc:1048-1049), and the text is available through LastError().
+//   * The handle is sized for the largest image seen so far (it starts at 1920x1080 and grows on demand).
+//   * Failures of the GPU layer, and an image that is not CV_8UC1 (the reference asserts, :1052), produce an
+//     empty result, the reference's only failure mode (src/ORBextractor.cc:1048-1049); the text is in LastError().
 #pragma once
+#include <cstring>
 #include <string>
 #include <vector>
 
@@ -26,77 +32,56 @@ class ORBextractor {
 public:
     enum { HARRIS_SCORE = 0, FAST_SCORE = 1 };   // include/ORBextractor.h:49 (unused there too)
 
+    // include/ORBextractor.h:51-52; device / maxWidth / maxHeight are this layer's own, defaulted
     ORBextractor(int nfeatures, float scaleFactor, int nlevels, int iniThFAST, int minThFAST,
                  int device = 0, int maxWidth = 1920, int maxHeight = 1080)
-        : nfeatures_(nfeatures), nlevels_(nlevels), scaleFactor_(scaleFactor)
+        : nfeatures_(nfeatures), nlevels_(nlevels), iniTh_(iniThFAST), minTh_(minThFAST), device_(device), scaleFactor_(scaleFactor)
     {
-        if (orbx_create(&h_, nfeatures, scaleFactor, nlevels, iniThFAST, minThFAST, device, maxWidth, maxHeight, 1) != ORBX_OK) {
-            err_ = orbx_last_error();
-            h_ = nullptr;
-            return;
-        }
-        mvScaleFactor.resize(nlevels); mvInvScaleFactor.resize(nlevels);
-        mvLevelSigma2.resize(nlevels); mvInvLevelSigma2.resize(nlevels);
-        orbx_get_tables(h_, mvScaleFactor.data(), mvInvScaleFactor.data(), mvLevelSigma2.data(), mvInvLevelSigma2.data());
-        mvImagePyramid.resize(nlevels);
-        cap_ = orbx_capacity(h_);
-        kp_.resize(cap_);
+        mvImagePyramid.resize(nlevels > 0 ? nlevels : 0);
+        open(maxWidth, maxHeight);
     }
     ~ORBextractor() { orbx_destroy(h_); }
     ORBextractor(const ORBextractor &) = delete;
     ORBextractor &operator=(const ORBextractor &) = delete;
 
-    // Compute the ORB features and descriptors on an image; mask is ignored (as in the reference).
-    void operator()(cv::InputArray image, cv::InputArray /*mask*/, std::vector<cv::KeyPoint> &keypoints,
-                    cv::OutputArray descriptors)
+    // Compute the ORB features and descriptors on an image; mask is ignored (as in the reference, :1045-1107).
+    void operator()(cv::InputArray _image, cv::InputArray /*mask*/, std::vector<cv::KeyPoint> &_keypoints,
+                    cv::OutputArray _descriptors)
     {
-        const cv::Mat &im = image;
-        keypoints.clear();
-        if (im.empty() || !h_) { descriptors.release(); return; }        // :1048-1049
-        cv::Mat tmp(cap_, 32, cv::CV_8U);
+        _keypoints.clear();
+        if (_image.empty()) { _descriptors.release(); return; }                  // :1048-1049
+        cv::Mat image = _image.getMat();
+        if (image.type() != CV_8UC1) { err_ = "image is not CV_8UC1"; _descriptors.release(); return; }   // :1052 assert
+        if (!fits(image.cols, image.rows)) { _descriptors.release(); return; }
         int n = 0;
-        const int rc = orbx_extract(h_, im.data, im.cols, im.rows, (int)im.step, kp_.data(), tmp.data, cap_, &n);
-        if (rc != ORBX_OK) { err_ = orbx_last_error(); descriptors.release(); return; }
-        fill(tmp, n, keypoints, descriptors);
+        const int rc = orbx_extract(h_, image.data, image.cols, image.rows, (int)image.step, kp_.data(), desc_.data(), cap_, &n);
+        if (rc != ORBX_OK) { err_ = orbx_last_error(); _descriptors.release(); return; }
+        fill(n, _keypoints, _descriptors);
     }
 
     // operator() in two halves (orbx_extract_begin / orbx_extract_end): Begin returns as soon as the image is staged and the
     // work is queued; End waits and fills the outputs.  One call in flight per extractor (the stereo pair has two anyway).
-    bool Begin(cv::InputArray image)
+    bool Begin(cv::InputArray _image)
     {
-        const cv::Mat &im = image;
+        cv::Mat image = _image.getMat();
+        if (!image.empty() && image.type() != CV_8UC1) { err_ = "image is not CV_8UC1"; return false; }
+        if (!image.empty() && !fits(image.cols, image.rows)) return false;
         if (!h_) return false;
-        const int rc = im.empty() ? orbx_extract_begin(h_, nullptr, 0, 0, 0) : orbx_extract_begin(h_, im.data, im.cols, im.rows, (int)im.step);
+        const int rc = image.empty() ? orbx_extract_begin(h_, nullptr, 0, 0, 0)
+                                     : orbx_extract_begin(h_, image.data, image.cols, image.rows, (int)image.step);
         if (rc != ORBX_OK) err_ = orbx_last_error();
         return rc == ORBX_OK;
     }
-    void End(std::vector<cv::KeyPoint> &keypoints, cv::OutputArray descriptors)
+    void End(std::vector<cv::KeyPoint> &_keypoints, cv::OutputArray _descriptors)
     {
-        keypoints.clear();
-        if (!h_) { descriptors.release(); return; }
-        cv::Mat tmp(cap_, 32, cv::CV_8U);
+        _keypoints.clear();
+        if (!h_) { _descriptors.release(); return; }
         int n = 0;
-        const int rc = orbx_extract_end(h_, kp_.data(), tmp.data, cap_, &n);
-        if (rc != ORBX_OK) { err_ = orbx_last_error(); descriptors.release(); return; }
-        fill(tmp, n, keypoints, descriptors);
+        const int rc = orbx_extract_end(h_, kp_.data(), desc_.data(), cap_, &n);
+        if (rc != ORBX_OK) { err_ = orbx_last_error(); _descriptors.release(); return; }
+        fill(n, _keypoints, _descriptors);
     }
 
-private:
-    void fill(const cv::Mat &tmp, int n, std::vector<cv::KeyPoint> &keypoints, cv::OutputArray descriptors)
-    {
-        if (n == 0) { descriptors.release(); return; }                   // :1066-1067
-        descriptors.create(n, 32, cv::CV_8U);                            // :1070
-        for (int i = 0; i < n; i++) memcpy(descriptors.ptr<uint8_t>(i), tmp.ptr<uint8_t>(i), 32);
-        keypoints.resize(n);
-        static_assert(sizeof(orbx_keypoint) == 28, "orbx_keypoint mirrors cv::KeyPoint");
-        for (int i = 0; i < n; i++) {
-            cv::KeyPoint &k = keypoints[i];
-            k.pt.x = kp_[i].x; k.pt.y = kp_[i].y; k.size = kp_[i].size; k.angle = kp_[i].angle;
-            k.response = kp_[i].response; k.octave = kp_[i].octave; k.class_id = kp_[i].class_id;
-        }
-    }
-
-public:
     int inline GetLevels() { return nlevels_; }
     float inline GetScaleFactor() { return scaleFactor_; }
     std::vector<float> inline GetScaleFactors() { return mvScaleFactor; }
@@ -104,7 +89,7 @@ public:
     std::vector<float> inline GetScaleSigmaSquares() { return mvLevelSigma2; }
     std::vector<float> inline GetInverseScaleSigmaSquares() { return mvInvLevelSigma2; }
 
-    // include/ORBextractor.h:85.  Call after operator() when the pyramid is needed on the host.
+    // include/ORBextractor.h:85.  Call FetchImagePyramid() after operator() when the pyramid is needed on the host.
     std::vector<cv::Mat> mvImagePyramid;
     bool FetchImagePyramid()
     {
@@ -112,7 +97,7 @@ public:
         for (int l = 0; l < nlevels_; l++) {
             int w = 0, hgt = 0;
             if (orbx_level_size(h_, l, &w, &hgt) != ORBX_OK) return false;
-            mvImagePyramid[l].create(hgt, w, cv::CV_8U);
+            mvImagePyramid[l].create(hgt, w, CV_8UC1);
             if (orbx_download_level(h_, 0, l, mvImagePyramid[l].data, (int)mvImagePyramid[l].step, 0) != ORBX_OK) return false;
         }
         return true;
@@ -122,10 +107,48 @@ public:
     const std::string &LastError() const { return err_; }
 
 protected:
+    bool open(int maxW, int maxH)
+    {
+        if (h_) { orbx_destroy(h_); h_ = nullptr; }
+        if (orbx_create(&h_, nfeatures_, scaleFactor_, nlevels_, iniTh_, minTh_, device_, maxW, maxH, 1) != ORBX_OK) {
+            err_ = orbx_last_error();
+            h_ = nullptr;
+            return false;
+        }
+        maxW_ = maxW; maxH_ = maxH;
+        mvScaleFactor.resize(nlevels_); mvInvScaleFactor.resize(nlevels_);
+        mvLevelSigma2.resize(nlevels_); mvInvLevelSigma2.resize(nlevels_);
+        orbx_get_tables(h_, mvScaleFactor.data(), mvInvScaleFactor.data(), mvLevelSigma2.data(), mvInvLevelSigma2.data());
+        cap_ = orbx_capacity(h_);
+        kp_.resize(cap_);
+        desc_.resize((size_t)cap_ * 32);
+        return true;
+    }
+    bool fits(int w, int h)   // a larger image than any before: re-create the handle for it (the reference has no size limit)
+    {
+        if (h_ && w <= maxW_ && h <= maxH_) return true;
+        return open(w > maxW_ ? w : maxW_, h > maxH_ ? h : maxH_);
+    }
+    void fill(int n, std::vector<cv::KeyPoint> &_keypoints, cv::OutputArray _descriptors)
+    {
+        if (n == 0) { _descriptors.release(); return; }                  // :1066-1067
+        _descriptors.create(n, 32, CV_8U);                               // :1070
+        cv::Mat descriptors = _descriptors.getMat();                     // :1071
+        for (int i = 0; i < n; i++) memcpy(descriptors.ptr<unsigned char>(i), &desc_[(size_t)i * 32], 32);
+        _keypoints.resize(n);
+        static_assert(sizeof(orbx_keypoint) == 28, "orbx_keypoint mirrors cv::KeyPoint");
+        for (int i = 0; i < n; i++) {
+            cv::KeyPoint &k = _keypoints[i];
+            k.pt.x = kp_[i].x; k.pt.y = kp_[i].y; k.size = kp_[i].size; k.angle = kp_[i].angle;
+            k.response = kp_[i].response; k.octave = kp_[i].octave; k.class_id = kp_[i].class_id;
+        }
+    }
+
     orbx_extractor *h_ = nullptr;
-    int nfeatures_, nlevels_, cap_ = 0;
+    int nfeatures_, nlevels_, iniTh_, minTh_, device_, cap_ = 0, maxW_ = 0, maxH_ = 0;
     float scaleFactor_;
     std::vector<orbx_keypoint> kp_;
+    std::vector<unsigned char> desc_;
     std::vector<float> mvScaleFactor, mvInvScaleFactor, mvLevelSigma2, mvInvLevelSigma2;
     std::string err_;
 };

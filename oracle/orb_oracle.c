@@ -1556,3 +1556,82 @@ int oro_search_by_projection_map(int n_mp, const uint8_t *in_view, const float *
     free(cand);
     return nmatches;
 }
+
+/* ---- ORBmatcher::SearchByProjection(Frame &CurrentFrame, KeyFrame *pKF, const set<MapPoint*> &sAlreadyFound, th, ORBdist),
+ * src/ORBmatcher.cc:1472-1599, Tracking::Relocalization's second-chance matcher (src/Tracking.cc:1459,1473).
+ * Per key-frame feature i: usable[i] = vpMPs[i] && !isBad() && !sAlreadyFound.count(pMP); xw = GetWorldPos(); min_dist_inv /
+ * max_dist_inv = GetMin/MaxDistanceInvariance(); mf_max_distance = the MapPoint's mfMaxDistance (PredictScale, src/MapPoint.cc:402-417);
+ * mp_desc = GetDescriptor(); kf_angle[i] = pKF->mvKeysUn[i].angle.  Current frame: Tcw row-major 4x4, grid g of kps_cur (mvKeysUn),
+ * log_scale_factor = mfLogScaleFactor, cur_has_point[i2] = (mvpMapPoints[i2] != NULL) in/out, cur_match[i2] out = i or -1.
+ * cv::Mat algebra as OpenCV's float GEMM (double accumulation, one rounding); cv::norm of a float vector accumulates in double;
+ * log() of a float resolves to logf in the reference's translation unit (decision). */
+int oro_predict_scale(float mf_max_distance, float current_dist, float log_scale_factor, int n_levels)
+{
+    const float ratio = mf_max_distance / current_dist;                 /* src/MapPoint.cc:407 */
+    int nScale = (int)ceilf(logf(ratio) / log_scale_factor);           /* :410 */
+    if (nScale < 0) nScale = 0;
+    else if (nScale >= n_levels) nScale = n_levels - 1;
+    return nScale;
+}
+int oro_search_by_projection_kf(int n_kf, const uint8_t *usable, const float *xw, const float *min_dist_inv, const float *max_dist_inv,
+                                const float *mf_max_distance, const uint8_t *mp_desc, const float *kf_angle, const float *Tcw,
+                                float fx, float fy, float cx, float cy, const float bounds[4], const float *scale_factors, int nlevels,
+                                float log_scale_factor, const oro_grid *g, const oro_keypoint *kps_cur, const uint8_t *desc_cur, int n_cur,
+                                float th, int orb_dist, int check_orientation, uint8_t *cur_has_point, int32_t *cur_match)
+{
+    int nmatches = 0, nrot = 0, hist[30];
+    int *rot = (int *)malloc(sizeof(int) * 2 * (size_t)(n_kf > 0 ? n_kf : 1));
+    int32_t *cand = (int32_t *)malloc(sizeof(int32_t) * (size_t)(n_cur > 0 ? n_cur : 1));
+    for (int i = 0; i < 30; i++) hist[i] = 0;
+    for (int i = 0; i < n_cur; i++) cur_match[i] = -1;
+    float Ow[3];                                                        /* Ow = -Rcw^T tcw, :1478 */
+    for (int k = 0; k < 3; k++) {
+        const double s = (double)(-Tcw[k]) * Tcw[3] + (double)(-Tcw[4 + k]) * Tcw[7] + (double)(-Tcw[8 + k]) * Tcw[11];
+        Ow[k] = (float)s;
+    }
+    for (int i = 0; i < n_kf; i++) {
+        if (!usable[i]) continue;                                      /* :1492-1494 */
+        const float *X = xw + 3 * (size_t)i;
+        const float xc = oro_gemm_row(Tcw, 0, X), yc = oro_gemm_row(Tcw, 1, X), zc = oro_gemm_row(Tcw, 2, X);
+        const float invzc = (float)(1.0 / zc);                         /* :1502 (no sign check in this variant) */
+        const float u = fx * xc * invzc + cx, v = fy * yc * invzc + cy;
+        if (u < bounds[0] || u > bounds[1]) continue;
+        if (v < bounds[2] || v > bounds[3]) continue;
+        double nn = 0;                                                  /* cv::norm(x3Dw - Ow), :1513-1514 */
+        for (int k = 0; k < 3; k++) { const float po = X[k] - Ow[k]; nn += (double)po * (double)po; }
+        const float dist3D = (float)sqrt(nn);
+        if (dist3D < min_dist_inv[i] || dist3D > max_dist_inv[i]) continue;    /* :1520 */
+        const int nPredictedLevel = oro_predict_scale(mf_max_distance[i], dist3D, log_scale_factor, nlevels);
+        const float radius = th * scale_factors[nPredictedLevel];      /* :1526 */
+        const int nc = oro_features_in_area(g, kps_cur, u, v, radius, nPredictedLevel - 1, nPredictedLevel + 1, cand, n_cur);
+        if (nc <= 0) continue;
+        const uint8_t *dMP = mp_desc + (size_t)i * 32;
+        int bestDist = 256, bestIdx2 = -1;
+        for (int c = 0; c < nc; c++) {                                 /* :1538-1554 */
+            const int i2 = cand[c];
+            if (cur_has_point[i2]) continue;
+            const int dist = oro_descriptor_distance(dMP, desc_cur + (size_t)i2 * 32);
+            if (dist < bestDist) { bestDist = dist; bestIdx2 = i2; }
+        }
+        if (bestDist <= orb_dist && bestIdx2 >= 0) {                   /* :1556; with ORBdist >= 256 the reference would index [-1] */
+            cur_has_point[bestIdx2] = 1;
+            cur_match[bestIdx2] = i;
+            nmatches++;
+            if (check_orientation) {
+                const int bin = oro_rot_bin(kf_angle[i], kps_cur[bestIdx2].angle);
+                rot[2 * nrot] = bin; rot[2 * nrot + 1] = bestIdx2; nrot++;
+                hist[bin]++;
+            }
+        }
+    }
+    if (check_orientation) {                                           /* :1577-1596 */
+        int ind1, ind2, ind3;
+        oro_three_maxima(hist, 30, &ind1, &ind2, &ind3);
+        for (int k = 0; k < nrot; k++) {
+            const int bin = rot[2 * k];
+            if (bin != ind1 && bin != ind2 && bin != ind3) { cur_has_point[rot[2 * k + 1]] = 0; cur_match[rot[2 * k + 1]] = -1; nmatches--; }
+        }
+    }
+    free(rot); free(cand);
+    return nmatches;
+}

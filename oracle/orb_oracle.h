@@ -170,6 +170,15 @@ int oro_search_by_projection_map(int n_mp, const uint8_t *in_view, const float *
                                  const int32_t *pred_level, const float *view_cos, const uint8_t *mp_desc, const int32_t *mp_obs,
                                  const float *scale_factors, const oro_grid *g, const oro_keypoint *kps_cur, const uint8_t *desc_cur,
                                  const float *u_right, int n_cur, float th, float nnratio, int32_t *cur_obs, int32_t *cur_match);
+/* ORBmatcher::SearchByProjection(Frame &CurrentFrame, KeyFrame *pKF, const set<MapPoint*> &sAlreadyFound, th, ORBdist)
+ * (src/ORBmatcher.cc:1472-1599), Tracking::Relocalization's matcher after PnP (src/Tracking.cc:1459,1473), and
+ * MapPoint::PredictScale(dist, Frame*) (src/MapPoint.cc:402-417).  Arguments: see orb_oracle.c. */
+int oro_predict_scale(float mf_max_distance, float current_dist, float log_scale_factor, int n_levels);
+int oro_search_by_projection_kf(int n_kf, const uint8_t *usable, const float *xw, const float *min_dist_inv, const float *max_dist_inv,
+                                const float *mf_max_distance, const uint8_t *mp_desc, const float *kf_angle, const float *Tcw,
+                                float fx, float fy, float cx, float cy, const float bounds[4], const float *scale_factors, int nlevels,
+                                float log_scale_factor, const oro_grid *g, const oro_keypoint *kps_cur, const uint8_t *desc_cur, int n_cur,
+                                float th, int orb_dist, int check_orientation, uint8_t *cur_has_point, int32_t *cur_match);
 /* AssignFeaturesToGrid + PosInGrid; items must hold n ints */
 void oro_grid_build(oro_grid *g, const oro_keypoint *kps_un, int n, float min_x, float max_x, float min_y, float max_y, int *items);
 /* GetFeaturesInArea: returns the count written to out (reference order), -1 if cap is too small */

@@ -1,12 +1,13 @@
 // Exercises the C++ adapters (my-slam_amd/host) the way src/Frame.cc:247-253 uses the reference
-// class: ORBextractor(...)(im, cv::Mat(), keys, descriptors).  Prints a checksum the pytest wrapper
-// compares with the Python/C-ABI result.  With argv[1] == "compile-only" nothing runs.
+// class: ORBextractor(...)(im, cv::Mat(), keys, descriptors), with the reference's five-argument constructor
+// (src/Tracking.cc:121).  Prints a checksum the pytest wrapper compares with the Python/C-ABI result.
+// With argv[1] == "compile-only" nothing runs.  (The Tracking-thread matcher call sites: tracking_callsites.cc.)
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
-#include "../my-slam_amd/host/ORBextractor.h"
-#include "../my-slam_amd/host/ORBmatcher.h"
-#include "../my-slam_amd/host/PnPsolver.h"
+#include "ORBextractor.h"
+#include "ORBmatcher.h"
+#include "PnPsolver.h"
 
 int main(int argc, char **argv)
 {
@@ -42,11 +43,11 @@ int main(int argc, char **argv)
     }
     if (argc < 4) { fprintf(stderr, "usage: %s raw.u8 W H\n", argv[0]); return 2; }
     const int W = atoi(argv[2]), H = atoi(argv[3]);
-    cv::Mat im(H, W, cv::CV_8U);
+    cv::Mat im(H, W, CV_8UC1);
     FILE *f = fopen(argv[1], "rb");
     if (!f || fread(im.data, 1, (size_t)W * H, f) != (size_t)W * H) { fprintf(stderr, "read failed\n"); return 2; }
     fclose(f);
-    ORB_SLAM2::ORBextractor extractor(1000, 1.2f, 8, 20, 7, 0, W, H);
+    ORB_SLAM2::ORBextractor extractor(1000, 1.2f, 8, 20, 7);
     if (!extractor.Valid()) { fprintf(stderr, "create failed: %s\n", extractor.LastError().c_str()); return 3; }
     std::vector<cv::KeyPoint> keys;
     cv::Mat descriptors;
@@ -72,15 +73,21 @@ int main(int argc, char **argv)
     int self = 0;
     for (size_t i = 0; i < bi.size(); i++) self += (bd[i] == 0);
     extractor.FetchImagePyramid();
-    // Tracking::MonocularInitialization's matcher on the frame against itself: every level-0 keypoint finds itself
-    matcher.BuildGrid(keys, 0.f, (float)W, 0.f, (float)H);
-    std::vector<cv::Point2f> prevMatched(keys.size());
-    for (size_t i = 0; i < keys.size(); i++) prevMatched[i] = keys[i].pt;
-    std::vector<int> matches12;
-    const int nInit = matcher.SearchForInitialization(keys, descriptors, keys, descriptors, prevMatched, matches12, 100);
-    int selfInit = 0, level0 = 0;
-    for (size_t i = 0; i < keys.size(); i++) { level0 += keys[i].octave == 0; selfInit += matches12[i] == (int)i; }
-    printf("%zu %016llx %d %d %d %d %d %d\n", keys.size(), h, self, extractor.mvImagePyramid[7].cols,
-           ORB_SLAM2::ORBmatcher::DescriptorDistance(descriptors.row(0), descriptors.row(1)), nInit, selfInit, level0);
+    // a 3-channel / float image is not CV_8UC1: empty result (the reference asserts, src/ORBextractor.cc:1052)
+    std::vector<cv::KeyPoint> keysF;
+    cv::Mat descF, imF(H, W, CV_32FC1);
+    extractor(imF, cv::Mat(), keysF, descF);
+    const int rejected = keysF.empty() && descF.empty();
+    // a larger image than the handle was sized for (1920 x 1080 at first): the handle grows, no failure
+    cv::Mat big(1200, 2000, CV_8UC1);
+    for (int y = 0; y < big.rows; y++) for (int x = 0; x < big.cols; x++) big.at<unsigned char>(y, x) = im.at<unsigned char>(y % H, x % W);
+    std::vector<cv::KeyPoint> keysB;
+    cv::Mat descB;
+    extractor(big, cv::Mat(), keysB, descB);
+    const int grew = keysB.size() > 900 && descB.rows == (int)keysB.size();
+    extractor(im, cv::Mat(), keys, descriptors);
+    extractor.FetchImagePyramid();
+    printf("%zu %016llx %d %d %d %d %d\n", keys.size(), h, self, extractor.mvImagePyramid[7].cols,
+           ORB_SLAM2::ORBmatcher::DescriptorDistance(descriptors.row(0), descriptors.row(1)), rejected, grew);
     return 0;
 }

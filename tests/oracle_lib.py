@@ -85,6 +85,11 @@ def lib(native=False):
     L.oro_search_by_projection_last.restype = C.c_int
     L.oro_search_by_projection_map.argtypes = [C.c_int, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, C.c_int, C.c_float, C.c_float, vp, vp]
     L.oro_search_by_projection_map.restype = C.c_int
+    L.oro_search_by_projection_kf.argtypes = [C.c_int, vp, vp, vp, vp, vp, vp, vp, vp, C.c_float, C.c_float, C.c_float, C.c_float, vp, vp, C.c_int,
+                                              C.c_float, vp, vp, vp, C.c_int, C.c_float, C.c_int, C.c_int, vp, vp]
+    L.oro_search_by_projection_kf.restype = C.c_int
+    L.oro_predict_scale.argtypes = [C.c_float, C.c_float, C.c_float, C.c_int]
+    L.oro_predict_scale.restype = C.c_int
     L.oro_undistort_points.argtypes = [vp, C.c_int, C.c_float, C.c_float, C.c_float, C.c_float, vp]
     L.oro_undistort_points.restype = None
     L.oro_image_bounds.argtypes = [C.c_int, C.c_int, C.c_float, C.c_float, C.c_float, C.c_float, vp, vp]
@@ -302,6 +307,22 @@ def search_by_projection_map(in_view, proj_x, proj_y, pred_level, view_cos, mp_d
     pp = lambda a: _p(a) if a is not None else None
     n = lib().oro_search_by_projection_map(len(in_view), _p(in_view), _p(px), _p(py), pp(pxr), _p(lv), _p(vc), _p(mp_desc), _p(mp_obs), _p(sf),
                                            C.byref(grid_cur.g), _p(grid_cur.kps), _p(desc_cur), pp(ur), len(grid_cur.kps), th, nnratio, _p(cur_obs), _p(cm))
+    return cm, n
+
+
+def search_by_projection_kf(usable, xw, min_dist_inv, max_dist_inv, mf_max_distance, mp_desc, kf_angle, Tcw, K, bounds, scale_factors,
+                            log_scale_factor, grid_cur, desc_cur, cur_has_point, th, orb_dist, check_ori):
+    """ORBmatcher::SearchByProjection(CurrentFrame, pKF, sAlreadyFound, th, ORBdist) on the oracle -> (cur_match, nmatches);
+    cur_has_point (uint8, in/out) = mvpMapPoints[i2] != NULL"""
+    f32 = lambda a: np.ascontiguousarray(a, np.float32)
+    usable = np.ascontiguousarray(usable, np.uint8); xw = f32(xw); mn, mx, mf = f32(min_dist_inv), f32(max_dist_inv), f32(mf_max_distance)
+    mp_desc = np.ascontiguousarray(mp_desc, np.uint8); ka = f32(kf_angle); Tcw = f32(Tcw).reshape(16)
+    b = f32(bounds); sf = f32(scale_factors); desc_cur = np.ascontiguousarray(desc_cur, np.uint8)
+    cm = np.full(len(grid_cur.kps), -1, np.int32)
+    fx, fy, cx, cy = K
+    n = lib().oro_search_by_projection_kf(len(usable), _p(usable), _p(xw), _p(mn), _p(mx), _p(mf), _p(mp_desc), _p(ka), _p(Tcw), fx, fy, cx, cy,
+                                          _p(b), _p(sf), len(sf), log_scale_factor, C.byref(grid_cur.g), _p(grid_cur.kps), _p(desc_cur),
+                                          len(grid_cur.kps), th, int(orb_dist), int(check_ori), _p(cur_has_point), _p(cm))
     return cm, n
 
 

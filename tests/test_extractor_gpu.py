@@ -72,6 +72,31 @@ def test_batch_equals_single(orbx, synth):
         _compare(res[k][0], res[k][1], okps, odesc, "frame %d" % k)
 
 
+def test_batch_chunked_pipeline_equals_plain(orbx, synth):
+    """orbx_extract_batch cuts a host batch into chunks (staging threads, two streams, one HIP graph per chunk); the result must be
+    the plain one-piece path's, for a ragged last chunk, a padded row pitch and repeated calls (graph replay)."""
+    W, H, B = 322, 241, 21
+    pad = np.zeros((B, H, W + 14), np.uint8)
+    pad[:, :, :W] = synth.stream(9, W, H, B)
+    frames = pad[:, :, :W]                                   # row stride 336 != width
+    assert frames.strides[1] == W + 14
+    ex = orbx.ORBextractor(500, max_width=W, max_height=H, max_batch=B)
+    ex.set_batch_chunk(0)
+    plain = ex.extract_batch_raw(frames)
+    plain = tuple(a.copy() for a in plain)
+    for chunk in (4, 8, 10):
+        ex.set_batch_chunk(chunk)
+        for rep in range(3):                                 # capture, replay, replay
+            k, d, c = ex.extract_batch_raw(frames)
+            assert np.array_equal(c, plain[2]), (chunk, rep)
+            for f in range(B):
+                n = int(c[f])
+                assert k[f, :n].tobytes() == plain[0][f, :n].tobytes() and np.array_equal(d[f, :n], plain[1][f, :n]), (chunk, rep, f)
+    okps, odesc, _ = O.Extractor(500).extract(np.ascontiguousarray(frames[B - 1]))
+    n = int(plain[2][B - 1])
+    _compare(plain[0][B - 1, :n], plain[1][B - 1, :n], okps, odesc, "last frame")
+
+
 # ---- committed fixtures: no oracle build needed for these ----
 import glob
 import os

@@ -178,6 +178,54 @@ def test_search_by_projection_last_equals_oracle(orbx, synth, mono, th, with_rig
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("th,orb_dist,ori,dz", [(10.0, 100, True, 0.0), (3.0, 64, True, 0.0), (10.0, 100, False, 0.0), (10.0, 100, True, 6.0), (3.0, 64, True, -4.0)])
+def test_search_by_projection_kf_equals_oracle(orbx, synth, th, orb_dist, ori, dz):
+    """ORBmatcher::SearchByProjection(CurrentFrame, pKF, sAlreadyFound, th, ORBdist) (src/ORBmatcher.cc:1472-1599) with the call
+    pairs of Tracking::Relocalization (Tracking.cc:1459: th 10, ORBdist 100; :1473: th 3, ORBdist 64; ORBmatcher(0.9, true)) on the
+    three-depth scene: the key frame's MapPoints are its keypoints back-projected to their layer's depth, some of them bad, NULL or
+    already found; the current frame already holds some points; a pose step along z moves points across pyramid levels and out of
+    their distance-invariance range.  projection -> PredictScale -> search through the C ABI == the oracle's single restatement."""
+    W, H = 1241, 376
+    fx, fy, cx, cy, base, shifts = 718.856, 718.856, 607.1928, 185.2157, 0.5, (2, 4, 6)
+    frames, layer = synth.stream_layers(5, W, H, 2, shifts=shifts)
+    ex = orbx.ORBextractor(2000, max_width=W, max_height=H)
+    k0, d0 = ex(frames[0]); k1, d1 = ex(frames[1])
+    sf = ex.GetScaleFactors()
+    logsf = float(np.log(np.float32(1.2)))
+    Z = (fx * base / np.array(shifts, np.float64))[layer[np.clip(np.rint(k0["y"]).astype(int), 0, H - 1), np.clip(np.rint(k0["x"]).astype(int), 0, W - 1)]]
+    xw = np.stack([(k0["x"] - cx) * Z / fx, (k0["y"] - cy) * Z / fy, Z], 1).astype(np.float32)
+    rng = np.random.default_rng(int(th) + orb_dist)
+    usable = (rng.random(len(k0)) < 0.8).astype(np.uint8)                # pMP && !isBad() && !sAlreadyFound.count(pMP)
+    # MapPoint::UpdateNormalAndDepth: mfMaxDistance = dist * scaleFactor^level, mfMinDistance = mfMaxDistance / scaleFactor^(nlevels-1)
+    d_ref = np.linalg.norm(xw.astype(np.float64), axis=1)
+    mf_max = (d_ref * sf[k0["octave"]]).astype(np.float32)
+    mf_min = (mf_max / sf[7]).astype(np.float32)
+    min_inv, max_inv = (np.float32(0.8) * mf_min).astype(np.float32), (np.float32(1.2) * mf_max).astype(np.float32)
+    Tcw = np.eye(4, dtype=np.float32); Tcw[0, 3] = -base; Tcw[2, 3] = -dz
+    K, bounds = (fx, fy, cx, cy), (0.0, float(W), 0.0, float(H))
+    m = orbx.ORBmatcher(0.9, ori, max_queries=4096, max_train=4096, max_pairs=1 << 21)
+    m.grid_build(k1, *bounds)
+    og = O.FrameGrid(k1, *bounds)
+    has0 = (rng.random(len(k1)) < 0.15).astype(np.uint8)                 # slots of the current frame that already hold a MapPoint
+    ha, hb = has0.copy(), has0.copy()
+    u, v, iz, d3, inside = m.ProjectPoints(Tcw, K, bounds, xw)
+    lv = m.PredictScale(mf_max, d3, logsf, 8)
+    use = (usable.astype(bool) & inside.astype(bool) & ~(d3 < min_inv) & ~(d3 > max_inv)).astype(np.uint8)
+    cm, nm = m.SearchByProjectionKF(use, u, v, lv, d0, k0["angle"], sf, k1, d1, ha, th, orb_dist)
+    ocm, onm = O.search_by_projection_kf(usable, xw, min_inv, max_inv, mf_max, d0, k0["angle"], Tcw, K, bounds, sf, logsf, og, d1, hb, th, orb_dist, ori)
+    assert nm == onm and np.array_equal(cm, ocm) and np.array_equal(ha, hb)
+    assert nm == int((cm >= 0).sum()) and (has0[cm >= 0] == 0).all() and (usable[cm[cm >= 0]] == 1).all()
+    assert np.array_equal(ha, has0 | (cm >= 0))
+    if dz == 0.0:
+        assert nm > (250 if th >= 10 else 150)                           # the true pose puts most free points on their match
+    elif dz > 0:
+        assert (use == 0).sum() > (usable == 0).sum()                    # the step towards the scene pushed some points out of view / range
+    # degenerate inputs
+    e_cm, e_nm = m.SearchByProjectionKF(use[:0], u[:0], v[:0], lv[:0], d0[:0], k0["angle"][:0], sf, k1, d1, ha.copy(), th, orb_dist)
+    assert e_nm == 0 and (e_cm == -1).all()
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("th,ratio,with_right", [(1.0, 0.8, False), (3.0, 0.8, False), (5.0, 0.6, True), (1.0, 1.0, True)])
 def test_search_by_projection_map_equals_oracle(orbx, synth, th, ratio, with_right):
     """ORBmatcher::SearchByProjection(F, vpMapPoints, th) (src/ORBmatcher.cc:45-125) as Tracking::SearchLocalPoints calls it

@@ -53,6 +53,7 @@ def test_cxx_tracking_harness_pose_stages(orbx, synth, tmp_path):
     # chained over 16 frames; 1 px of the nearest layer is 1/6 of a baseline
     assert p["max_translation_error_in_baselines"] < 0.25
     assert p["relocalizations"] == "2/2" and p["max_reloc_error_in_baselines"] < 0.25
+    assert p["reloc_search_by_projection_kf_matches"] > 100      # SearchByProjection(F, pKF, sFound, 10, 100) after PnP finds more points
 
 
 def test_pose_from_gpu_matches_python(orbx, synth, tmp_path):

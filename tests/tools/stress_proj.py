@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Randomised GPU-vs-oracle sweep of the three window matchers built on the Frame grid: SearchForInitialization,
-SearchByProjection(CurrentFrame, LastFrame) and SearchByProjection(F, vpMapPoints).  usage: stress_proj.py [seconds] [seed]"""
+SearchByProjection(CurrentFrame, LastFrame), SearchByProjection(F, vpMapPoints), SearchByProjection(CurrentFrame, pKF, ...) and the
+fused window search.  usage: stress_proj.py [seconds] [seed]"""
 import os, sys, time
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -13,7 +14,7 @@ import my_slam_amd.synth as synth
 
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
-t0 = time.time(); n_ok = [0, 0, 0]
+t0 = time.time(); n_ok = [0, 0, 0, 0, 0]
 while time.time() - t0 < budget:
     W = int(rng.integers(240, 1300)); H = int(rng.integers(180, 720)); nf = int(rng.choice([300, 1000, 2000, 4000]))
     shift = (int(rng.integers(0, 30)), int(rng.integers(0, 12)))
@@ -74,6 +75,23 @@ while time.time() - t0 < budget:
     a = m.search_area_best2(d0[:nq], qx, qy, qr, qmn, qmx, d1, skip)
     b = og.search_area_best2(d0[:nq], qx, qy, qr, qmn, qmx, d1, skip)
     assert all(np.array_equal(u, v) for u, v in zip(a, b)), ("area", W, H, nf, nq)
-    n_ok.append(1) if len(n_ok) == 3 else n_ok.__setitem__(3, n_ok[3] + 1)
-print("stress_proj: %d / %d / %d / %d random cases (SearchForInitialization / SearchByProjection last frame / local map / fused window search) "
-      "identical to the oracle in %.0f s" % (n_ok[0], n_ok[1], n_ok[2], n_ok[3] if len(n_ok) > 3 else 0, time.time() - t0))
+    n_ok[3] += 1
+    # 5. SearchByProjection(CurrentFrame, pKF, sAlreadyFound, th, ORBdist): the same plane seen from a pose that is off along z
+    usable = (rng.random(n) < 0.8).astype(np.uint8)
+    d_ref = np.linalg.norm(xw.astype(np.float64), axis=1)
+    mf_max = (d_ref * sf[k0["octave"]]).astype(np.float32); mf_min = (mf_max / sf[-1]).astype(np.float32)
+    mn_inv, mx_inv = (np.float32(0.8) * mf_min).astype(np.float32), (np.float32(1.2) * mf_max).astype(np.float32)
+    Tk = Tcw.copy(); Tk[2, 3] = -float(rng.choice([0.0, 0.3 * Z, -0.2 * Z, 2.0 * Z]))
+    logsf = float(np.log(np.float32(sf[1])))
+    thk, od = (10.0, 100) if rng.integers(0, 2) else (3.0, 64)
+    h0 = (rng.random(len(k1)) < 0.2).astype(np.uint8); ha, hb = h0.copy(), h0.copy()
+    K4 = (fx, fy, cx, cy); bnd = (0.0, float(W), 0.0, float(H))
+    u, v, _, d3, ins = m.ProjectPoints(Tk, K4, bnd, xw)
+    lvk = m.PredictScale(mf_max, d3, logsf, len(sf))
+    use = (usable.astype(bool) & ins.astype(bool) & ~(d3 < mn_inv) & ~(d3 > mx_inv)).astype(np.uint8)
+    a, na = m.SearchByProjectionKF(use, u, v, lvk, d0, k0["angle"], sf, k1, d1, ha, thk, od)
+    b, nb = O.search_by_projection_kf(usable, xw, mn_inv, mx_inv, mf_max, d0, k0["angle"], Tk, K4, bnd, sf, logsf, og, d1, hb, thk, od, ori)
+    assert na == nb and np.array_equal(a, b) and np.array_equal(ha, hb), ("kf", W, H, nf, shift, thk, od, float(Tk[2, 3]))
+    n_ok[4] += 1
+print("stress_proj: %d / %d / %d / %d / %d random cases (SearchForInitialization / SearchByProjection last frame / local map / fused window search / "
+      "SearchByProjection key frame) identical to the oracle in %.0f s" % (n_ok[0], n_ok[1], n_ok[2], n_ok[3], n_ok[4], time.time() - t0))

@@ -9,7 +9,9 @@
 //                                          windows around the previous positions: orbm_search_area_best2 + orbm_rot_filter
 //     Optimizer::PoseOptimization       -> orbp_pose_optimization        (src/Tracking.cc:783-787: start from the last pose)
 //     Relocalization's PnPsolver        -> orbp_pnp_* (0.99,10,300,4,0.5,5.991; iterate(5)) + orbp_pose_optimization
-//                                          (src/Tracking.cc:1392-1445), run every 8th frame to time it
+//                                          (src/Tracking.cc:1392-1445), run every 8th frame to time it, followed by
+//                                          orbm_project_points + orbm_search_by_projection_kf (SearchByProjection(
+//                                          mCurrentFrame, pKF, sFound, 10, 100), src/Tracking.cc:1459)
 // The pose stages need a scene with depth: prep_inputs.py writes the layered stream of my_slam_amd.synth.stream_layers
 // and its per-pixel layer map; the "MapPoints" of the previous frame are its keypoints back-projected to the depth of
 // their layer through the *estimated* previous pose, so the reported translation error is the drift of the whole chain.
@@ -75,7 +77,7 @@ int main(int argc, char **argv)
     std::vector<float> qx(cap), qy(cap), qr(cap), aq(cap), at(cap);
     std::vector<double> t_stage[5];     // per-stage samples; medians are reported (one slow frame must not skew a stage)
     std::vector<double> t_all, t_pose, t_reloc;
-    long nm_bow = 0, nm_proj = 0, n_inl = 0, n_reloc = 0, n_reloc_ok = 0;
+    long nm_bow = 0, nm_proj = 0, n_inl = 0, n_reloc = 0, n_reloc_ok = 0, n_reloc_add = 0;
     float Tprev[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};       // frame 0 = world
     std::vector<float> obs(2 * cap), is2(cap), xw(3 * cap), s2(cap);
     std::vector<uint8_t> outl(cap), inl(cap);
@@ -148,6 +150,39 @@ int main(int argc, char **argv)
                         const double e = (std::fabs(Tr[3] + k * base) + std::fabs(Tr[7]) + std::fabs(Tr[11])) / base;
                         max_reloc_err = std::max(max_reloc_err, e);
                         n_reloc_ok++;
+                        // src/Tracking.cc:1455-1462: with few inliers the reference projects the candidate key frame's other MapPoints
+                        // through the PnP pose, ORBmatcher(0.9, true).SearchByProjection(mCurrentFrame, pKF, sFound, 10, 100), and
+                        // optimises again.  Here on every relocalisation (to time and count it): the previous frame is the key
+                        // frame, all its keypoints carry a MapPoint, sFound = the BoW matches PnP worked on.
+                        {
+                            const int np = prev.n;
+                            std::vector<float> xk((size_t)np * 3), mfmax(np), pu(np), pv(np), d3(np), ang(np);
+                            std::vector<uint8_t> inside(np), use(np, 1), has(cur.n, 0);
+                            std::vector<int32_t> lv(np, 0), cmk(cur.n, -1);
+                            for (int i = 0; i < np; i++) {
+                                const orbx_keypoint &p = prev.kps[i];
+                                const int px = std::min(std::max((int)lrintf(p.x), 0), W - 1), py = std::min(std::max((int)lrintf(p.y), 0), H - 1);
+                                const double Z = depth[layer[(size_t)py * W + px]];
+                                const double Xc[3] = {(p.x - cx) * Z / fx - Tprev[3], (p.y - cy) * Z / fy - Tprev[7], Z - Tprev[11]};
+                                for (int a = 0; a < 3; a++) xk[3 * (size_t)i + a] = (float)(Tprev[a] * Xc[0] + Tprev[4 + a] * Xc[1] + Tprev[8 + a] * Xc[2]);
+                                const double Pc[3] = {(p.x - cx) * Z / fx, (p.y - cy) * Z / fy, Z};                               // in the key frame's camera
+                                mfmax[i] = (float)std::sqrt(Pc[0] * Pc[0] + Pc[1] * Pc[1] + Pc[2] * Pc[2]) * sfac[p.octave];   // MapPoint::UpdateNormalAndDepth
+                                ang[i] = p.angle;
+                            }
+                            for (int i = 0; i < cur.n; i++)
+                                if (match_f[i] >= 0) { has[i] = 1; use[match_f[i]] = 0; }                                          // sFound
+                            const float bnd[4] = {0.f, (float)W, 0.f, (float)H};
+                            CHK(orbm_project_points(Tr, fx, fy, cx, cy, bnd, xk.data(), np, pu.data(), pv.data(), nullptr, d3.data(), inside.data()));
+                            for (int i = 0; i < np; i++) {
+                                if (!use[i]) continue;
+                                if (!inside[i] || d3[i] < 0.8f * (mfmax[i] / sfac[7]) || d3[i] > 1.2f * mfmax[i]) { use[i] = 0; continue; }
+                                lv[i] = orbm_predict_scale(mfmax[i], d3[i], logf(1.2f), 8);
+                            }
+                            int nadd = 0;
+                            CHK(orbm_search_by_projection_kf(mt, np, use.data(), pu.data(), pv.data(), lv.data(), prev.desc.data(), ang.data(), sfac, 8,
+                                                             cur.kps.data(), cur.desc.data(), cur.n, 10.0f, 100, 1, has.data(), cmk.data(), &nadd));
+                            n_reloc_add += nadd;
+                        }
                     }
                     n_reloc++;
                     t_reloc.push_back(now_ms() - tr0);
@@ -202,9 +237,10 @@ int main(int argc, char **argv)
     if (pose) {
         std::sort(t_pose.begin(), t_pose.end()); std::sort(t_reloc.begin(), t_reloc.end());
         printf("{\"pose\": {\"ms_median_pose_optimization\": %.3f, \"ms_median_relocalization\": %.3f, \"inliers_per_frame\": %.1f, "
-               "\"max_translation_error_in_baselines\": %.4f, \"relocalizations\": \"%ld/%ld\", \"max_reloc_error_in_baselines\": %.4f}}\n",
+               "\"max_translation_error_in_baselines\": %.4f, \"relocalizations\": \"%ld/%ld\", \"max_reloc_error_in_baselines\": %.4f, "
+               "\"reloc_search_by_projection_kf_matches\": %.1f}}\n",
                t_pose.empty() ? 0 : t_pose[t_pose.size() / 2], t_reloc.empty() ? 0 : t_reloc[t_reloc.size() / 2],
-               (double)n_inl / std::max(K - 1, 1), max_err, n_reloc_ok, n_reloc, max_reloc_err);
+               (double)n_inl / std::max(K - 1, 1), max_err, n_reloc_ok, n_reloc, max_reloc_err, (double)n_reloc_add / std::max(n_reloc_ok, 1L));
     }
     printf("{\"harness\": \"C++ through the C ABI\", \"shape\": \"%dx%d n=%d\", \"frames_timed\": %d, \"ms_per_frame_median\": %.3f, \"frames_per_s\": %.1f, "
            "\"ms_median\": {\"extract\": %.3f, \"grid\": %.3f, \"bow\": %.3f, \"search_by_bow\": %.3f, \"search_by_projection\": %.3f}, "
