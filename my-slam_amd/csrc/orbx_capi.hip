@@ -123,6 +123,9 @@ struct orbx_extractor {
     int cur_w = 0, cur_h = 0; int last_batch = 0;
     const uint8_t *last_input = nullptr; int last_in_stride = 0; long long last_in_frame = 0;
     OrbxPlan plan; OrbxWork work; ResizeTab tabs[ORBX_MAX_LEVELS]; int area2[ORBX_MAX_LEVELS];
+    // several pyramid levels per launch (k_resize_fused): one plan per band height (16 rows for batches, 8 for a few frames)
+    struct FusePlan { bool ok = false; int a = 0, b = 0, nbands = 0, buf0 = 0, lds = 0, bh = 0; size_t off = 0; } fuse[2];
+    int4 *d_bands = nullptr; size_t bands_cap = 0; int fuse_on = 1;
     size_t oct_lds = 0;
     // allocations (sized for the max shape)
     OrbxPlan max_plan; size_t pyr_bytes = 0; size_t pyr_level_off[ORBX_MAX_LEVELS];
@@ -273,7 +276,7 @@ static void free_all(orbx_extractor *h)
 {
     if (!h) return;
     hipSetDevice(h->device);
-    hipFree(h->d_input); hipFree(h->d_pyr); hipFree(h->d_tab_i); hipFree(h->d_tab_s); hipFree(h->d_cells);
+    hipFree(h->d_input); hipFree(h->d_pyr); hipFree(h->d_tab_i); hipFree(h->d_tab_s); hipFree(h->d_cells); hipFree(h->d_bands);
     hipFree(h->work.cand); hipFree(h->work.cand_count); hipFree(h->work.owner); hipFree(h->work.arena);
     hipFree(h->work.sel); hipFree(h->work.nk); hipFree(h->work.ncand); hipFree(h->work.errflags);
     hipFree(h->d_out);
@@ -342,6 +345,9 @@ extern "C" int orbx_create(orbx_extractor **out, int nfeatures, float scale_fact
     ALLOC(h->d_pyr, off + 256);   // slack: the 4x4 resize reads whole dwords around a row segment
     ALLOC(h->d_tab_i, tab_e * sizeof(int));
     ALLOC(h->d_tab_s, tab_e * sizeof(short2));
+    h->bands_cap = 2 * ((size_t)max_height / 8 + 4) * ORBX_MAX_LEVELS;
+    ALLOC(h->d_bands, h->bands_cap * sizeof(int4));
+    { const char *e = getenv("ORBX_PYRAMID_FUSE"); if (e) h->fuse_on = atoi(e); }
     h->cells_cap = h->max_plan.ncells + 64 * nlevels;   // a smaller frame never has more cells; slack for rounding
     ALLOC(h->d_cells, (size_t)h->cells_cap * sizeof(uint32_t));
     const OrbxPlan &M = h->max_plan;
@@ -466,6 +472,7 @@ static int ensure_plan(orbx_extractor *h, int W, int H)
     std::vector<int> ti(h->tab_elems ? h->tab_elems : 1);
     std::vector<short2> ts(h->tab_elems ? h->tab_elems : 1);
     size_t e = 0;
+    size_t yofs_at[ORBX_MAX_LEVELS] = {};
     for (int l = 1; l < h->nlevels; l++) {
         OrbxLevel &L = P.lv[l];
         L.stride = (int)align_up(L.w, 64);
@@ -474,6 +481,7 @@ static int ensure_plan(orbx_extractor *h, int W, int H)
         const OrbxLevel &S = P.lv[l - 1];
         const size_t ex = align_up((size_t)L.w + 4, 4), ey = align_up((size_t)L.h + 4, 4);
         plan_resize(S.w, S.h, L.w, L.h, &ti[e], &ts[e], &ti[e + ex], &ts[e + ex], &h->area2[l]);
+        yofs_at[l] = e + ex;
         h->tabs[l].xofs = h->d_tab_i + e; h->tabs[l].alpha = h->d_tab_s + e;
         h->tabs[l].yofs = h->d_tab_i + e + ex; h->tabs[l].beta = h->d_tab_s + e + ex;
         e += ex + ey;
@@ -486,8 +494,53 @@ static int ensure_plan(orbx_extractor *h, int W, int H)
         for (int i = 0; i < L.nRows; i++)
             for (int j = 0; j < L.nCols; j++) cells[(size_t)L.cell_begin + (size_t)i * L.nCols + j] = (uint32_t)l | ((uint32_t)i << 4) | ((uint32_t)j << 16);
     }
+    // ---- fused upper levels: row-band ownership / footprint tables (k_resize_fused) ----
+    std::vector<int4> bands;
+    for (int v = 0; v < 2; v++) {
+        orbx_extractor::FusePlan &F = h->fuse[v];
+        F = orbx_extractor::FusePlan();
+        F.bh = v == 0 ? 16 : 8;
+        const int b = h->nlevels - 1;
+        for (int a = 1; h->fuse_on && b - a >= 2 && b < ORBX_FUSE_MAX; a++) {
+            bool fast = true;
+            for (int l = a + 1; l <= b; l++) fast = fast && h->area2[l] == RESIZE_FAST && (P.lv[l].w + 3) / 4 <= 512;
+            if (!fast) continue;
+            const int nl = b - a + 1, nb = (P.lv[b].h + F.bh - 1) / F.bh;
+            std::vector<int4> t((size_t)nb * nl);
+            int need_rows[ORBX_MAX_LEVELS] = {};
+            for (int j = 0; j < nb; j++) {
+                int o0 = j * F.bh, o1 = std::min((j + 1) * F.bh, P.lv[b].h), n0 = o0, n1 = o1;
+                t[(size_t)j * nl + (b - a)] = make_int4(o0, o1, n0, n1);
+                need_rows[b] = std::max(need_rows[b], n1 - n0);
+                for (int l = b - 1; l >= a; l--) {
+                    const int *yo = &ti[yofs_at[l + 1]];
+                    const int hl = P.lv[l].h, hu = P.lv[l + 1].h;
+                    auto cl = [&](int v2) { return std::min(std::max(v2, 0), hl - 1); };
+                    const int p0 = o0 == 0 ? 0 : cl(yo[o0]), p1 = o1 == hu ? hl : cl(yo[o1]);
+                    const int q0 = std::min(cl(yo[n0]), p0), q1 = std::max(cl(yo[n1 - 1] + 1) + 1, p1);
+                    o0 = p0; o1 = p1; n0 = q0; n1 = q1;
+                    t[(size_t)j * nl + (l - a)] = make_int4(o0, o1, n0, n1);
+                    need_rows[l] = std::max(need_rows[l], n1 - n0);
+                }
+            }
+            int buf[2] = {0, 0};
+            for (int l = a + 1; l < b; l++) {
+                const int pitch = (int)align_up((size_t)P.lv[l].w + 12, 16);
+                buf[(l - a) & 1] = std::max(buf[(l - a) & 1], need_rows[l] * pitch);
+            }
+            int ysum = 0;
+            for (int l = a + 1; l <= b; l++) ysum += need_rows[l];
+            if (buf[0] + buf[1] > 64 * 1024 || ysum > ORBX_FUSE_YTAB) continue;      // too much for LDS from this level on: start the fusion one level up
+            if (bands.size() + t.size() > h->bands_cap) break;
+            F.ok = true; F.a = a; F.b = b; F.nbands = nb; F.buf0 = (int)align_up((size_t)buf[0], 16); F.lds = F.buf0 + (int)align_up((size_t)buf[1], 16) + 16;
+            F.off = bands.size();
+            bands.insert(bands.end(), t.begin(), t.end());
+            break;
+        }
+    }
     P.cell_tab = h->d_cells;
     HIPCHK(hipStreamSynchronize(h->stream));
+    if (!bands.empty()) HIPCHK(hipMemcpy(h->d_bands, bands.data(), bands.size() * sizeof(int4), hipMemcpyHostToDevice));
     HIPCHK(hipMemcpy(h->d_cells, cells.data(), (size_t)P.ncells * sizeof(uint32_t), hipMemcpyHostToDevice));
     HIPCHK(hipMemcpy(h->d_tab_i, ti.data(), e * sizeof(int), hipMemcpyHostToDevice));
     HIPCHK(hipMemcpy(h->d_tab_s, ts.data(), e * sizeof(short2), hipMemcpyHostToDevice));
@@ -561,9 +614,35 @@ static int enqueue(orbx_extractor *h, const uint8_t *d_images, int nframes, int 
         HIPCHK(hipStreamWaitEvent(s, h->ev_join[ORBX_MAX_SUB - 2], 0));
         orbx_launch_fast(sp[0], sw[0], nframes, P.lv[1].cell_begin, P.ncells, s);
     } else {
-        for (int l = 1; l < h->nlevels; l++)
-            for (int i = 0; i < nsub; i++)
-                orbx_launch_resize(sp[i].lv[l - 1], sp[i].lv[l], h->tabs[l], h->area2[l], f0[i + 1] - f0[i], l == 1 ? src_end : nullptr, st[i]);
+        for (int i = 0; i < nsub; i++) {
+            const int nf = f0[i + 1] - f0[i];
+            // The upper levels in one launch -- for a FEW frames only.  The resize arithmetic is ~22 vector instructions per pixel
+            // and the per-level kernels of a large batch are bound by that, not by their launches (rocprofv3 + SQ_INSTS_VALU:
+            // 47 % VALU-busy over the six upper levels at 64 x 640 x 480); the fused kernel recomputes the band overlaps
+            // (+25 % pixels) and measured 70 us against 57 for the chain there.  With one frame the launches dominate and
+            // fusing wins (28.6 -> 24.6 us at 640 x 480).  ORBX_PYRAMID_FUSE=2 forces it for A/B measurements.
+            const orbx_extractor::FusePlan *F = nullptr;
+            const orbx_extractor::FusePlan *cand = h->fuse[1].ok ? &h->fuse[1] : (h->fuse[0].ok ? &h->fuse[0] : nullptr);
+            if (h->fuse_on == 2 && h->fuse[0].ok && (long long)h->fuse[0].nbands * nf >= 384) cand = &h->fuse[0];
+            if (cand && (h->fuse_on == 2 || (long long)nf * sp[i].lv[cand->a + 1].w * sp[i].lv[cand->a + 1].h <= 1200000)) F = cand;
+            const int last_single = F ? F->a : h->nlevels - 1;
+            for (int l = 1; l <= last_single; l++)
+                orbx_launch_resize(sp[i].lv[l - 1], sp[i].lv[l], h->tabs[l], h->area2[l], nf, l == 1 ? src_end : nullptr, st[i]);
+            if (F) {
+                FuseArgs A;
+                memset(&A, 0, sizeof(A));
+                A.a = F->a; A.b = F->b; A.bands = h->d_bands + F->off; A.nbands = F->nbands; A.buf0_bytes = F->buf0;
+                for (int l = F->a; l <= F->b; l++) {
+                    const OrbxLevel &L = sp[i].lv[l];
+                    FuseLevel &U = A.lv[l];
+                    U.base = L.base; U.w = L.w; U.h = L.h; U.stride = L.stride; U.frame = L.frame_stride; U.tab = h->tabs[l];
+                    U.nbx = (L.w + 3) / 4;
+                    U.rcp_nbx = U.nbx > 1 ? (uint32_t)((1ull << 32) / (unsigned)U.nbx + 1) : 0u;
+                    U.pitch = (int)align_up((size_t)L.w + 12, 16);
+                }
+                orbx_launch_resize_fused(A, nf, (size_t)F->lds, st[i]);
+            }
+        }
         if (pe) HIPCHK(hipEventRecord(pe[1], s));
         for (int i = 0; i < nsub; i++) orbx_launch_fast(sp[i], sw[i], f0[i + 1] - f0[i], 0, P.ncells, st[i]);
     }

@@ -115,6 +115,14 @@ struct ResizeTab {                // per destination level
     const int *xofs; const short2 *alpha; const int *yofs; const short2 *beta;
 };
 
+// Several pyramid levels in one launch (orbx_pyramid.hip, k_resize_fused): levels a+1 .. b from level a, one workgroup per
+// (band of rows of level b, frame).  bands[band * (b - a + 1) + (l - a)] = rows of level l the band owns (x, y) and needs (z, w).
+#define ORBX_FUSE_MAX 12
+#define ORBX_FUSE_YTAB 1024      // rows a band needs, summed over its fused levels (checked at plan time)
+struct FuseLevel { uint8_t *base; int w, h, stride; long long frame; ResizeTab tab; int nbx; uint32_t rcp_nbx; int pitch; };
+struct FuseArgs { FuseLevel lv[ORBX_FUSE_MAX]; int a, b; const int4 *bands; int nbands; int buf0_bytes; };
+void orbx_launch_resize_fused(const FuseArgs &A, int nframes, size_t lds_bytes, hipStream_t s);
+
 // ---- launchers (orbx_pyramid.hip, orbx_fast.hip, orbx_octree.hip, orbx_describe.hip) ----
 enum { RESIZE_FAST = 0, RESIZE_AREA2 = 1, RESIZE_GENERIC = 2 };
 // src_end != NULL: the source is caller-owned memory; one past its last valid byte (fast path guard)

@@ -152,6 +152,191 @@ __global__ __launch_bounds__(256) void k_resize_linear_4x4(
     }
 }
 
+// -------------------------------------------------------------------------------------------------
+// Levels a+1 .. b in ONE launch.  The upper levels of the pyramid are small (level 7 of a 640 x 480 frame is 179 x 134): as
+// launches of their own each costs the ~4.5 us launch floor for 0.3 .. 4 us of work, six of them in a row.  Level l + 1 is a pure
+// function of level l's integer output (:1117-1123), so a workgroup that holds a band of rows of level l in LDS can produce the
+// band of level l + 1 under it without going back to memory: one workgroup = one band of BH rows of level b of one frame; it walks
+// down from level a (read from memory) to level b, keeping the rows of each level it NEEDS (the bilinear footprint of what the
+// next level needs) in one of two LDS buffers and writing the rows it OWNS to memory.  The owned row ranges of the bands of a
+// level partition that level (they are the images of the bands of level b under the monotone yofs maps), the needed ranges
+// overlap by the footprint: the overlap is computed twice (~28 % more pixels for 16-row bands over six levels) and written once.
+// Bands are full-width, so rows are read and written whole and only the row ranges need planning (host, at plan time).
+// The arithmetic per pixel is k_resize_linear_4x4's: aligned dwords funnel-shifted, v_perm_b32 pairs, v_dot2_u32_u16 for the
+// horizontal blend, 24-bit multiplies for the vertical one.  Thread work item = 4 destination pixels of one row.
+// -------------------------------------------------------------------------------------------------
+// One row of 4 destination pixels: the source dwords of the two source rows are loaded first (issue), blended later (finish),
+// so that the loads of several rows are in flight together.  The row tables (yofs, beta) of every level's band were copied to
+// LDS when the workgroup started: inside a level nothing but the source pixels is waited for.
+struct FuseRow { uint32_t w[2][3], sh[2]; int b0, b1; };
+template <bool MEM>
+__device__ __forceinline__ void fuse_issue(FuseRow &R, const FuseLevel &S, const uint8_t *Sg, const uint8_t *sbuf, int need0_src,
+                                           const int2 yt, int base)
+{
+    const int sy = yt.x;
+    R.b0 = (int)(short)((uint32_t)yt.y & 0xFFFFu); R.b1 = (int)(short)((uint32_t)yt.y >> 16);
+    const int sy0 = min(max(sy, 0), S.h - 1), sy1 = min(max(sy + 1, 0), S.h - 1);
+#pragma unroll
+    for (int rr = 0; rr < 2; rr++) {
+        const int srow = rr ? sy1 : sy0;
+        if (MEM) {
+            // pointer arithmetic on the typed pointer (an integer round trip would turn these into flat loads)
+            const uint32_t off = (uint32_t)(__mul24(srow, S.stride) + base);
+            R.sh[rr] = ((uint32_t)(uintptr_t)Sg + off) & 3u;
+            const uint32_t *q = reinterpret_cast<const uint32_t *>(Sg + (off - R.sh[rr]));
+            R.w[rr][0] = q[0]; R.w[rr][1] = q[1]; R.w[rr][2] = q[2];
+        } else {
+            const uint32_t off = (uint32_t)(__mul24(srow - need0_src, S.pitch) + base);
+            const uint32_t *q = reinterpret_cast<const uint32_t *>(sbuf + (off & ~3u));
+            R.sh[rr] = off & 3u;
+            R.w[rr][0] = q[0]; R.w[rr][1] = q[1]; R.w[rr][2] = q[2];
+        }
+    }
+}
+__device__ __forceinline__ uint32_t fuse_finish(const FuseRow &R, const uint32_t sel[4], const uint32_t al[4])
+{
+    typedef unsigned short us2 __attribute__((ext_vector_type(2)));
+    int hv[2][4];
+#pragma unroll
+    for (int rr = 0; rr < 2; rr++) {
+        const uint32_t lo = __builtin_amdgcn_alignbyte(R.w[rr][1], R.w[rr][0], R.sh[rr]), hi = __builtin_amdgcn_alignbyte(R.w[rr][2], R.w[rr][1], R.sh[rr]);
+#pragma unroll
+        for (int i = 0; i < 4; i++)
+            hv[rr][i] = (int)__builtin_amdgcn_udot2(__builtin_bit_cast(us2, __builtin_amdgcn_perm(hi, lo, sel[i])), __builtin_bit_cast(us2, al[i]), 0u, false);
+    }
+    uint32_t out = 0;
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        const int v = ((__mul24(R.b0, hv[0][i] >> 4) >> 16) + (__mul24(R.b1, hv[1][i] >> 4) >> 16) + 2) >> 2;
+        out |= (uint32_t)(v & 255) << (8 * i);
+    }
+    return out;
+}
+
+// a thread keeps ONE block of 4 columns for a whole level (its column tables live in registers) and walks down the rows
+struct FuseCols { int rg, G, x4; int4 sxv; uint4 alv; };
+__device__ __forceinline__ void fuse_cols(FuseCols &C, const FuseLevel &D)
+{
+    const int tid = threadIdx.x;
+    int rg = D.rcp_nbx ? (int)__umulhi((uint32_t)tid, D.rcp_nbx) : tid;       // tid / nbx
+    rg -= (rg * D.nbx > tid) ? 1 : 0;
+    C.rg = rg; C.G = 512 / D.nbx;                                             // row groups that fit the workgroup (nbx <= 512: checked on the host)
+    C.x4 = (tid - rg * D.nbx) * 4;
+    C.sxv = make_int4(0, 0, 0, 0); C.alv = make_uint4(0, 0, 0, 0);
+    if (rg < C.G) {
+        C.sxv = *reinterpret_cast<const int4 *>(D.tab.xofs + C.x4);           // tables are padded to 4
+        C.alv = *reinterpret_cast<const uint4 *>(D.tab.alpha + C.x4);         // (a0 | a1 << 16) per column
+    }
+}
+
+template <bool MEM>
+__device__ __forceinline__ void fuse_level(const FuseArgs &A, int l, const int4 rs, const int4 rd, int f, uint8_t *lds, const int2 *ytab,
+                                           const FuseCols &C)
+{
+    const FuseLevel &S = A.lv[l - 1], &D = A.lv[l];
+    const uint8_t *sbuf = lds + (((l - 1 - A.a) & 1) ? A.buf0_bytes : 0);
+    uint8_t *dbuf = lds + (((l - A.a) & 1) ? A.buf0_bytes : 0);
+    const uint8_t *Sg = S.base + (long long)f * S.frame;
+    uint8_t *Dg = D.base + (long long)f * D.frame;
+    const int rg = C.rg, G = C.G, x4 = C.x4;
+    if (rg >= G) return;
+    int sx[4] = {C.sxv.x, C.sxv.y, C.sxv.z, C.sxv.w};
+    uint32_t al[4] = {C.alv.x, C.alv.y, C.alv.z, C.alv.w}, sel[4];
+#pragma unroll
+    for (int i = 1; i < 4; i++)
+        if (x4 + i >= D.w) { sx[i] = sx[0]; al[i] = al[0]; }
+    const int base = sx[0];
+#pragma unroll
+    for (int i = 0; i < 4; i++) sel[i] = 0x0c010c00u + (uint32_t)(sx[i] - base) * 0x00010001u;
+    const int rows = rd.w - rd.z;
+    auto emit = [&](int ry, uint32_t out) {
+        const int y = rd.z + ry;
+        if (l < A.b) *reinterpret_cast<uint32_t *>(dbuf + (uint32_t)(__mul24(ry, D.pitch) + x4)) = out;
+        if (y >= rd.x && y < rd.y) {
+            uint8_t *Dr = Dg + (uint32_t)(__mul24(y, D.stride) + x4);
+            if (x4 + 3 < D.w) *reinterpret_cast<uint32_t *>(Dr) = out;
+            else
+                for (int i = 0; x4 + i < D.w; i++) Dr[i] = (uint8_t)(out >> (8 * i));
+        }
+    };
+    int ry = rg;
+    for (; ry + 3 * G < rows; ry += 4 * G) {                                  // four rows in flight
+        FuseRow R0, R1, R2, R3;
+        fuse_issue<MEM>(R0, S, Sg, sbuf, rs.z, ytab[ry], base);
+        fuse_issue<MEM>(R1, S, Sg, sbuf, rs.z, ytab[ry + G], base);
+        fuse_issue<MEM>(R2, S, Sg, sbuf, rs.z, ytab[ry + 2 * G], base);
+        fuse_issue<MEM>(R3, S, Sg, sbuf, rs.z, ytab[ry + 3 * G], base);
+        emit(ry, fuse_finish(R0, sel, al));
+        emit(ry + G, fuse_finish(R1, sel, al));
+        emit(ry + 2 * G, fuse_finish(R2, sel, al));
+        emit(ry + 3 * G, fuse_finish(R3, sel, al));
+    }
+    for (; ry < rows; ry += G) {
+        FuseRow R0;
+        fuse_issue<MEM>(R0, S, Sg, sbuf, rs.z, ytab[ry], base);
+        emit(ry, fuse_finish(R0, sel, al));
+    }
+}
+
+// -DFUSE_TRACE: per-level wall-clock (100 MHz) totals over all workgroups (tools/dbg/fuse_trace.py); slot 15 counts workgroups
+#ifdef FUSE_TRACE
+__device__ unsigned long long g_fuse_trace[16];
+extern "C" int orbx_debug_fuse_trace(unsigned long long *out, int reset)
+{
+    static unsigned long long z[16];
+    if (reset) return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_fuse_trace), z, sizeof(z));
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_fuse_trace), sizeof(z));
+}
+#define FUSE_T(i) do { __syncthreads(); if (threadIdx.x == 0) { const unsigned long long n_ = wall_clock64(); atomicAdd(&g_fuse_trace[i], n_ - ft_); ft_ = n_; } } while (0)
+#else
+#define FUSE_T(i) do { } while (0)
+#endif
+
+__global__ __launch_bounds__(512) void k_resize_fused(FuseArgs A)
+{
+    extern __shared__ __attribute__((aligned(16))) uint8_t fuse_lds[];
+    __shared__ int2 ytab[ORBX_FUSE_YTAB];          // (yofs, beta) of the rows this band needs, level after level
+    __shared__ int ybase[ORBX_FUSE_MAX];
+    const int band = blockIdx.x, f = blockIdx.y, tid = threadIdx.x;
+    const int nl = A.b - A.a + 1;
+    const int4 *bd = A.bands + band * nl;
+#ifdef FUSE_TRACE
+    unsigned long long ft_ = wall_clock64();
+    if (threadIdx.x == 0) atomicAdd(&g_fuse_trace[15], 1ull);
+#endif
+    // every table read of the workgroup up front: the row tables of all its levels into LDS, the column tables of the first level
+    // into registers (those of level l + 1 are fetched while level l is computed)
+    int yb = 0;
+    for (int l = A.a + 1; l <= A.b; l++) {
+        const int4 rd = bd[l - A.a];
+        const int rows = rd.w - rd.z;
+        if (tid == 0) ybase[l] = yb;
+        for (int r = tid; r < rows; r += 512) {
+            const FuseLevel &D = A.lv[l];
+            ytab[yb + r] = make_int2(D.tab.yofs[rd.z + r], *reinterpret_cast<const int *>(D.tab.beta + rd.z + r));
+        }
+        yb += rows;
+    }
+    FuseCols C, Cn;
+    fuse_cols(C, A.lv[A.a + 1]);
+    __syncthreads();
+    for (int l = A.a + 1; l <= A.b; l++) {
+        if (l < A.b) fuse_cols(Cn, A.lv[l + 1]);
+        if (l == A.a + 1) fuse_level<true>(A, l, bd[l - 1 - A.a], bd[l - A.a], f, fuse_lds, ytab + ybase[l], C);     // (own0, own1, need0, need1), workgroup-uniform
+        else fuse_level<false>(A, l, bd[l - 1 - A.a], bd[l - A.a], f, fuse_lds, ytab + ybase[l], C);
+        C = Cn;
+        __syncthreads();
+        FUSE_T(l - A.a - 1);
+    }
+}
+
+void orbx_launch_resize_fused(const FuseArgs &A, int nframes, size_t lds_bytes, hipStream_t s)
+{
+    if (lds_bytes > 48 * 1024)
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_resize_fused), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+    hipLaunchKernelGGL(k_resize_fused, dim3(A.nbands, nframes), dim3(512), lds_bytes, s, A);
+}
+
 void orbx_launch_resize(const OrbxLevel &src, const OrbxLevel &dst, const ResizeTab &tab, int mode,
                         int nframes, const uint8_t *src_end, hipStream_t s)
 {
