@@ -125,7 +125,7 @@ struct orbx_extractor {
     OrbxPlan plan; OrbxWork work; ResizeTab tabs[ORBX_MAX_LEVELS]; int area2[ORBX_MAX_LEVELS];
     // several pyramid levels per launch (k_resize_fused): one plan per band height (16 rows for batches, 8 for a few frames)
     struct FusePlan { bool ok = false; int a = 0, b = 0, nbands = 0, buf0 = 0, lds = 0, bh = 0; size_t off = 0; } fuse[2];
-    int4 *d_bands = nullptr; size_t bands_cap = 0; int fuse_on = 1;
+    int4 *d_bands = nullptr; size_t bands_cap = 0; int fuse_on = 1; int oct_fast = 1; int oct_cap_max = 0;
     size_t oct_lds = 0;
     // allocations (sized for the max shape)
     OrbxPlan max_plan; size_t pyr_bytes = 0; size_t pyr_level_off[ORBX_MAX_LEVELS];
@@ -228,6 +228,15 @@ static int make_plan(const orbx_extractor *h, int W, int H, OrbxPlan *P, std::st
         const long long nmax = ((zw_all + L.nCols + 1) / 2) * ((zh_all + L.nRows + 1) / 2);
         L.cand_cap = L.nCols > 0 ? (int)std::min<long long>(nmax + 64, (1 << 20) - 1) : 0;
         if (L.nCols > 0 && zone / 8 + 256 >= 100000) P->oct_big = 1;   // 1080p-class level: the quadtree runs 1024-thread workgroups
+        // quadtree fast-forward depth (k_octree): 4 levels of the tree from one key histogram, 5 for 1080p-class levels; fewer when
+        // many roots (a wide level) would make the tables large.  ORBX_OCT_FAST=0 turns it off (A/B measurements).
+        L.fastD = 0;
+        if (L.nCols > 0 && h->oct_fast) {
+            int d = (zone / 8 + 256 >= 100000) ? 5 : 4;
+            while (d > 0 && (long long)L.nIni * (((1ll << (2 * (d + 1))) - 1) / 3) > 2800) d--;
+            L.fastD = d;
+            P->oct_ft = std::max(P->oct_ft, (int)(L.nIni * (((1ll << (2 * (d + 1))) - 1) / 3)));
+        }
         L.cand_off = cand_off; cand_off += (L.cand_cap + 15) / 16 * 16;
         L.list_cap = L.nCols > 0 ? (std::max(L.quota + 3, 4 * L.nIni) + 1 + 3) / 4 * 4 : 0;
         L.list_off = list_off; list_off += L.list_cap;
@@ -315,6 +324,7 @@ extern "C" int orbx_create(orbx_extractor **out, int nfeatures, float scale_fact
     h->ini_th = std::min(std::max(ini_th, 0), 255); h->min_th = std::min(std::max(min_th, 0), 255);
     h->device = device; h->max_w = max_width; h->max_h = max_height; h->max_batch = max_batch;
     memset(&h->work, 0, sizeof(h->work));
+    { const char *e = getenv("ORBX_OCT_FAST"); if (e) h->oct_fast = atoi(e); }
     build_tables(h);
 
     std::string why;
@@ -322,7 +332,8 @@ extern "C" int orbx_create(orbx_extractor **out, int nfeatures, float scale_fact
     if (rc != ORBX_OK) { delete h; return fail(rc, "max shape %dx%d: %s", max_width, max_height, why.c_str()); }
     int max_list = 0;
     for (int l = 0; l < nlevels; l++) max_list = std::max(max_list, h->max_plan.lv[l].list_cap);
-    h->oct_lds = orbx_octree_lds_bytes(std::max(max_list, 8));
+    h->oct_cap_max = std::max(max_list, 8);
+    h->oct_lds = orbx_octree_lds_bytes(h->oct_cap_max, 0);
     if (h->oct_lds > 150 * 1024) { delete h; return fail(ORBX_E_INVALID, "nfeatures=%d needs %zu B of LDS for the quadtree (max 153600)", nfeatures, h->oct_lds); }
 
 #define ALLOC(ptr, bytes)                                                                       \
@@ -647,7 +658,14 @@ static int enqueue(orbx_extractor *h, const uint8_t *d_images, int nframes, int 
         for (int i = 0; i < nsub; i++) orbx_launch_fast(sp[i], sw[i], f0[i + 1] - f0[i], 0, P.ncells, st[i]);
     }
     if (pe) HIPCHK(hipEventRecord(pe[2], s));
-    for (int i = 0; i < nsub; i++) orbx_launch_octree(sp[i], sw[i], f0[i + 1] - f0[i], h->oct_lds, st[i]);
+    {   // dynamic LDS of the launch: the list arrays for the handle's largest list + this shape's fast-forward tables
+        size_t lds = orbx_octree_lds_bytes(h->oct_cap_max, P.oct_ft);
+        if (lds > 150 * 1024) {              // no room for the tables beside very long lists: plain passes
+            for (int i = 0; i < nsub; i++) { sp[i].oct_ft = 0; for (int l = 0; l < h->nlevels; l++) sp[i].lv[l].fastD = 0; }
+            lds = orbx_octree_lds_bytes(h->oct_cap_max, 0);
+        }
+        for (int i = 0; i < nsub; i++) { sp[i].oct_cap_max = h->oct_cap_max; orbx_launch_octree(sp[i], sw[i], f0[i + 1] - f0[i], lds, st[i]); }
+    }
     if (pe) HIPCHK(hipEventRecord(pe[3], s));
     for (int i = 0; i < nsub; i++)
         orbx_launch_describe(sp[i], sw[i], f0[i + 1] - f0[i], d_kps + (long long)f0[i] * P.out_cap,

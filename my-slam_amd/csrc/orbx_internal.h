@@ -77,6 +77,7 @@ struct OrbxLevel {
     int cell_begin;               // index of this level's first cell in the per-frame cell list
     int quota;                    // mnFeaturesPerLevel[level]
     int nIni;                     // DistributeOctTree root count
+    int fastD;                    // quadtree: depth to which the early passes run on a key histogram instead of key loops (0 = off)
     float hX;                     // root width
     int cand_cap;  long long cand_off;    // per-frame candidate capacity / element offset
     int list_cap;  long long list_off;    // quadtree list capacity / element offset (sel buffer)
@@ -90,6 +91,8 @@ struct OrbxPlan {
     int ini_th, min_th;
     int ncells;                   // cells per frame over all levels
     int blur_mode;
+    int oct_ft;                   // quadtree fast-forward table entries (max over levels of nIni * (4^(fastD+1) - 1) / 3)
+    int oct_cap_max;              // largest list capacity the launch's LDS is sized for (the handle's maximum shape)
     int oct_big;                  // some level is 1080p-class (tens of thousands of candidates): quadtree workgroups of 1024 threads
     int out_cap;                  // per-frame output capacity
     long long cand_frame;         // candidates per frame (elements)
@@ -135,6 +138,6 @@ void orbx_launch_octree(const OrbxPlan &plan, const OrbxWork &wk, int nframes, s
 void orbx_launch_describe(const OrbxPlan &plan, const OrbxWork &wk, int nframes,
                           orbx_keypoint *d_kps, uint8_t *d_desc, int32_t *d_counts,
                           int32_t *d_status, hipStream_t s);
-size_t orbx_octree_lds_bytes(int list_cap_max);
+size_t orbx_octree_lds_bytes(int list_cap_max, int ft_entries);
 int orbx_upload_constants(const int umax[16], const int gauss_k[7]);
 int orbx_selftest_fp16(void);   // 0 = fp16 subnormal arithmetic behaves as k_fast_cells needs

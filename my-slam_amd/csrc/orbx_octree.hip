@@ -177,8 +177,27 @@ __device__ __forceinline__ void oct_body(const OrbxPlan &plan, const OrbxWork &w
                                          uint32_t *cnt0, uint32_t *cnt1, uint32_t *listA, uint32_t *listB, uint32_t *slotNode,
                                          int *childBase, OrbxNode *lnA, OrbxNode *lnB,
                                          const OrbxCand *__restrict__ cand, uint32_t *__restrict__ owner,
-                                         int32_t *__restrict__ posOf, OrbxCand *__restrict__ sel)
+                                         int32_t *__restrict__ posOf, OrbxCand *__restrict__ sel,
+                                         uint32_t *pathA, uint32_t *pathB, uint32_t *ftCnt, uint32_t *ftId, const int D)
 {
+    // Fast-forward of the early passes (D > 0).  While every splittable node is split, what a pass does to the KEYS is known
+    // in advance: a key ends up in the depth-t node whose box contains it, and the boxes are a function of the root box alone
+    // (DivideNode halves with ceil, :485-486).  So ONE key loop computes every key's path of D quadrant choices (2 bits per
+    // level) and a histogram of the leaves; sums give the key count of every possible node down to depth D (ftCnt); the passes
+    // then run on the NODES alone -- slots, children, list order, arena numbering, the termination and phase-B tests are the
+    // reference's, fed with counts from the table instead of a key loop per pass -- and record the arena id of every node they
+    // create under its path (ftId).  When the tree has reached depth D, or finishes earlier, one key loop turns each key's path
+    // into the id of the deepest created node on it (and its quadrant there), which is exactly the state the per-pass key loops
+    // would have left.  Paths: g = root << 2t | quadrants, tables indexed fto(t) + g.
+    const int nIniF = L.nIni;
+    auto fto = [&](int t) { return nIniF * (int)((((1u << (2 * t)) - 1u)) / 3u); };   // entries above depth t
+    auto ft_lookup = [&](uint32_t g, int tmax) -> uint32_t {     // deepest created node on the path of leaf g, searched from depth tmax up
+        for (int t = tmax; t > 0; t--) {
+            const uint32_t id = ftId[fto(t) + (int)(g >> (2 * (D - t)))];
+            if (id != 0xFFFFFFFFu) return id;
+        }
+        return g >> (2 * D);                                    // the root itself (arena id = root index)
+    };
     // Key loops.  REG: every key is in wv[]/xyv[] already.  Otherwise each thread first issues the loads of 8 keys
     // (the loop is latency-bound), then processes them.  The trip counts are wave-uniform: wave_count() is wave-wide.
     constexpr bool REG = KR > 0;
@@ -250,15 +269,47 @@ __device__ __forceinline__ void oct_body(const OrbxPlan &plan, const OrbxWork &w
 
     // ---- roots (:554-587) ----
     for (int i = tid; i < nIni; i += T) cc[i] = 0;
+    if (D > 0) {
+        const int E = fto(D + 1);
+        for (int i = tid; i < E; i += T) { ftCnt[i] = 0; ftId[i] = 0xFFFFFFFFu; }
+    }
     __syncthreads();
-    KEYLOOP_BEGIN(false, true)
-        const int xr = (int)(xyv[u] & 0xFFFFu) - ORBX_MINB;
-        int b = (int)__fdiv_rn((float)xr, L.hX);
-        b = min(max(b, 0), nIni - 1);
-        if (!REG && valid) owner[k] = (uint32_t)b;
-        wv[u] = (uint32_t)b;
-        ai = valid ? b : -1;
-    KEYLOOP_END_COUNT(cc)
+    if (D > 0) {
+        const int offD = fto(D);
+        KEYLOOP_BEGIN(false, true)
+            const int xr = (int)(xyv[u] & 0xFFFFu) - ORBX_MINB, yr = (int)(xyv[u] >> 16) - ORBX_MINB;
+            int b = (int)__fdiv_rn((float)xr, L.hX);
+            b = min(max(b, 0), nIni - 1);
+            int x0 = (int)__fmul_rn(L.hX, (float)b), x1 = (int)__fmul_rn(L.hX, (float)(b + 1)), y0 = 0, y1 = boxH;
+            uint32_t g = (uint32_t)b;
+            for (int t = 0; t < D; t++) {                       // DivideNode's boxes along the key's path (:485-528)
+                const int midx = x0 + ((x1 - x0 + 1) >> 1), midy = y0 + ((y1 - y0 + 1) >> 1);
+                const uint32_t qx = xr < midx ? 0u : 1u, qy = yr < midy ? 0u : 1u;
+                x0 = qx ? midx : x0; x1 = qx ? x1 : midx;
+                y0 = qy ? midy : y0; y1 = qy ? y1 : midy;
+                g = (g << 2) | qx | (qy << 1);
+            }
+            if (!REG && valid) owner[k] = g;
+            wv[u] = g;
+            ai = valid ? offD + (int)g : -1;
+        KEYLOOP_END_COUNT(ftCnt)
+        __syncthreads();
+        for (int t = D - 1; t >= 0; t--) {                      // key counts of every possible node, leaves up to the roots
+            const int o = fto(t), o1 = fto(t + 1), cntT = nIni << (2 * t);
+            for (int p = tid; p < cntT; p += T) ftCnt[o + p] = ftCnt[o1 + 4 * p] + ftCnt[o1 + 4 * p + 1] + ftCnt[o1 + 4 * p + 2] + ftCnt[o1 + 4 * p + 3];
+            __syncthreads();
+        }
+        for (int i = tid; i < nIni; i += T) cc[i] = ftCnt[i];
+    } else {
+        KEYLOOP_BEGIN(false, true)
+            const int xr = (int)(xyv[u] & 0xFFFFu) - ORBX_MINB;
+            int b = (int)__fdiv_rn((float)xr, L.hX);
+            b = min(max(b, 0), nIni - 1);
+            if (!REG && valid) owner[k] = (uint32_t)b;
+            wv[u] = (uint32_t)b;
+            ai = valid ? b : -1;
+        KEYLOOP_END_COUNT(cc)
+    }
     __syncthreads();
     for (int i = tid; i < nIni; i += T) {
         OrbxNode nd;
@@ -269,6 +320,7 @@ __device__ __forceinline__ void oct_body(const OrbxPlan &plan, const OrbxWork &w
         nd.count = (int)cc[i];
         nd.slot = i;
         lnA[i] = nd;
+        pathA[i] = (uint32_t)i;
     }
     __syncthreads();
     if (tid == 0) {   // initial list: non-empty roots in order; nIni is small
@@ -281,19 +333,28 @@ __device__ __forceinline__ void oct_body(const OrbxPlan &plan, const OrbxWork &w
     OCT_T(1);
     uint32_t *cur = listA, *nxt = listB;
     int m = sh.m, arenaN = nIni, lastBase = 0, lastC = nIni, phaseB = 0;
-    // first DivideNode of every splittable root: slots, then one key loop that counts quadrants
+    int depth = 0;                 // depth of the nodes in the window lnA
+    bool fast = D > 0;             // the keys still carry their paths (wv = leaf g), not node ids
+    // first DivideNode of every splittable root: slots, then the quadrant counts (from the table, or one key loop)
     int nAlive = oct_assign_slots<T>(lnA, lastC, true, false, slotNode, reinterpret_cast<unsigned long long *>(cn), sh);
     __syncthreads();
     for (int i = tid; i < 4 * nAlive; i += T) cc[i] = 0;
     __syncthreads();
-    KEYLOOP_BEGIN(true, true)
-        const uint32_t id = wv[u];
-        const OrbxNode nd = lnA[valid ? id : 0u];
-        const bool alive = valid && nd.count > 1;
-        const uint32_t q = oct_quadrant(nd, xyv[u]);
-        ai = alive ? 4 * nd.slot + (int)q : -1;
-        SETOWN(alive ? (id | (q << 30)) : id);
-    KEYLOOP_END_COUNT(cc)
+    if (fast) {
+        const int o1 = fto(1);
+        for (int i = tid; i < nIni; i += T)
+            if (lnA[i].count > 1)
+                for (int q = 0; q < 4; q++) cc[4 * lnA[i].slot + q] = ftCnt[o1 + 4 * i + q];
+    } else {
+        KEYLOOP_BEGIN(true, true)
+            const uint32_t id = wv[u];
+            const OrbxNode nd = lnA[valid ? id : 0u];
+            const bool alive = valid && nd.count > 1;
+            const uint32_t q = oct_quadrant(nd, xyv[u]);
+            ai = alive ? 4 * nd.slot + (int)q : -1;
+            SETOWN(alive ? (id | (q << 30)) : id);
+        KEYLOOP_END_COUNT(cc)
+    }
     __syncthreads();
 
     OCT_T(2);
@@ -343,6 +404,9 @@ __device__ __forceinline__ void oct_body(const OrbxPlan &plan, const OrbxWork &w
                     ch.count = c;
                     ch.slot = cidx;
                     lnB[cidx] = ch;
+                    const uint32_t cp = (pathA[slotNode[s]] << 2) | (uint32_t)q;
+                    pathB[cidx] = cp;
+                    if (fast && depth + 1 <= D) ftId[fto(depth + 1) + (int)cp] = (uint32_t)(arenaN + cidx);
                     cc[4 * s + q] = (uint32_t)(arenaN + cidx);
                     nxt[C - 1 - cidx] = (uint32_t)(arenaN + cidx);   // push_front => reversed
                     myExp += c > 1;
@@ -379,6 +443,16 @@ __device__ __forceinline__ void oct_body(const OrbxPlan &plan, const OrbxWork &w
         const bool done = newM >= N || newM == m;
         const int phaseBnext = phaseB || (!done && newM + 3 * sh.nToExpand > N);
         __syncthreads();
+        if (done && fast) {
+            // the keys still carry their paths: the node of a key is the deepest created node on its path
+            __syncthreads();       // ftId of this pass's children
+            KEYLOOP_BEGIN(true, false)
+                SETOWN(ft_lookup(wv[u], min(depth + 1, D)));
+            KEYLOOP_END
+            m = newM;
+            { uint32_t *t2 = cur; cur = nxt; nxt = t2; }
+            break;
+        }
         if (done) {
             // move the keys of expanded nodes to their children; the rest keep their node
             KEYLOOP_BEGIN(true, false)
@@ -401,6 +475,26 @@ __device__ __forceinline__ void oct_body(const OrbxPlan &plan, const OrbxWork &w
         OCT_T(phaseBnext ? 6 : 5);
         for (int i = tid; i < 4 * nAliveNext; i += T) cn[i] = 0;
         __syncthreads();
+        if (fast && depth + 2 <= D) {
+            // still ahead of the keys: the quadrant counts of the new children come from the table
+            const int o2 = fto(depth + 2);
+            for (int j = tid; j < C; j += T)
+                if (lnB[j].count > 1)
+                    for (int q = 0; q < 4; q++) cn[4 * lnB[j].slot + q] = ftCnt[o2 + 4 * (int)pathB[j] + q];
+        } else if (fast) {
+            // the table ends here: bring the keys in.  A key's node is the deepest created node on its path; if that is one of
+            // the children just made and it will split, count the key's quadrant inside it (the next pass's DivideNode)
+            KEYLOOP_BEGIN(true, true)
+                const uint32_t id = ft_lookup(wv[u], min(depth + 1, D));
+                const bool child = valid && (int)id >= arenaN;
+                const OrbxNode ch = lnB[child ? id - (uint32_t)arenaN : 0u];
+                const bool deep = child && ch.count > 1;
+                const uint32_t q = oct_quadrant(ch, xyv[u]);
+                ai = deep ? 4 * ch.slot + (int)q : -1;
+                SETOWN(deep ? (id | (q << 30)) : id);
+            KEYLOOP_END_COUNT(cn)
+            fast = false;
+        } else {
         KEYLOOP_BEGIN(true, true)
             const uint32_t w = wv[u];
             const uint32_t id = w & OCT_ID_MASK;
@@ -414,9 +508,11 @@ __device__ __forceinline__ void oct_body(const OrbxPlan &plan, const OrbxWork &w
             ai = deep ? 4 * ch.slot + (int)q : -1;
             SETOWN(expd ? (deep ? (child | (q << 30)) : child) : w);
         KEYLOOP_END_COUNT(cn)
+        }
         __syncthreads();
         OCT_T(7);
-        m = newM; lastBase = arenaN; lastC = C; arenaN += C; nAlive = nAliveNext; phaseB = phaseBnext;
+        m = newM; lastBase = arenaN; lastC = C; arenaN += C; nAlive = nAliveNext; phaseB = phaseBnext; depth++;
+        { uint32_t *t5 = pathA; pathA = pathB; pathB = t5; }
         { uint32_t *t2 = cur; cur = nxt; nxt = t2; }
         { OrbxNode *t3 = lnA; lnA = lnB; lnB = t3; }
         { uint32_t *t4 = cc; cc = cn; cn = t4; }
@@ -497,6 +593,13 @@ __global__ __launch_bounds__(T) void k_octree(OrbxPlan plan, OrbxWork wk)
     int *childBase = reinterpret_cast<int *>(slotNode + cap);              // [cap]
     OrbxNode *lnA = reinterpret_cast<OrbxNode *>(childBase + cap);         // [cap]  node window
     OrbxNode *lnB = lnA + cap;                                             // [cap]  children of this pass
+    uint32_t *pathA = reinterpret_cast<uint32_t *>(lnB + cap);             // [cap]  path (root << 2 depth | quadrants) of the window's nodes
+    uint32_t *pathB = pathA + cap;                                         // [cap]  ... of this pass's children
+    // fast-forward tables (oct_body): key counts and arena ids of every possible node down to depth fastD.  They sit behind the
+    // arrays of the LARGEST list of the launch (the dynamic LDS size is one number per launch).
+    uint32_t *ftCnt = reinterpret_cast<uint32_t *>(oct_lds + (size_t)plan.oct_cap_max * 88);
+    uint32_t *ftId = ftCnt + plan.oct_ft;
+    const int D = L.fastD;
 
     const OrbxCand *cand = wk.cand + (long long)f * plan.cand_frame + L.cand_off;
     uint32_t *owner = wk.owner + (long long)f * plan.cand_frame + L.cand_off;
@@ -512,7 +615,7 @@ __global__ __launch_bounds__(T) void k_octree(OrbxPlan plan, OrbxWork wk)
         if (tid == 0) wk.nk[f * plan.nlevels + l] = 0;
         return;
     }
-#define OCT_ARGS plan, wk, sh, L, f, l, n, cap, N, cnt0, cnt1, listA, listB, slotNode, childBase, lnA, lnB, cand, owner, posOf, sel
+#define OCT_ARGS plan, wk, sh, L, f, l, n, cap, N, cnt0, cnt1, listA, listB, slotNode, childBase, lnA, lnB, cand, owner, posOf, sel, pathA, pathB, ftCnt, ftId, D
     // T = 512 serves the small shapes, many workgroups per CU: stay under 128 VGPRs.  T = 1024 owns its CU anyway.
     if constexpr (T == 512) {
         if (n <= 12 * T)
@@ -530,7 +633,7 @@ __global__ __launch_bounds__(T) void k_octree(OrbxPlan plan, OrbxWork wk)
 #undef OCT_ARGS
 }
 
-size_t orbx_octree_lds_bytes(int list_cap_max) { return (size_t)list_cap_max * 80; }
+size_t orbx_octree_lds_bytes(int list_cap_max, int ft_entries) { return (size_t)list_cap_max * 88 + (size_t)ft_entries * 8; }
 
 void orbx_launch_octree(const OrbxPlan &plan, const OrbxWork &wk, int nframes, size_t lds_bytes, hipStream_t s)
 {
