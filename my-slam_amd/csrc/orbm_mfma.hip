@@ -67,16 +67,17 @@ __device__ __forceinline__ void mf_fold(int &ba, int &sa, uint32_t &bk, uint32_t
     ba = MF_ACC_NONE; sa = MF_ACC_NONE;
 }
 
-// Workgroup = 4 waves x MF_QB query blocks against ONE SPLIT of the train descriptors of one frame pair; the split (<= MF_MAXT
-// tiles of 32 descriptors) sits in LDS whole, already expanded to operand bytes: every global load of the workgroup is issued up
-// front (one dword per thread and tile for the train side, the wave's 64 query descriptors as two 16-byte loads per lane), one
-// memory latency is paid once, and the MFMA phase runs from LDS and registers without another global wait or barrier.  The
-// expansion bits -> bytes is done here, on the fly (~24 VALU instructions per thread and tile against 16 MFMAs per wave and
-// tile): a pre-expanded copy in memory is 8x the bytes, and re-reading it per query block / per split made the kernel
-// memory-bound (163 MB per launch, 21 us with the MFMA pipe 23 % busy).  Three workgroups per CU: while one waits for its
-// loads the others compute.  The 1-D grid is ordered pair-major and dealt to the XCDs in contiguous eighths (placement only,
-// as in k_fast_cells), so the workgroups of a pair share an L2.
-#define MF_MAXT 6
+// Workgroup = 4 waves x MF_QB query blocks (256 queries) against one PART (1 / S) of the train descriptors of one frame pair.
+// The part is walked in stages of MF_STG tiles (32 descriptors each) through two LDS buffers that hold the tiles already
+// expanded to operand bytes.  What is read from memory is only the 32-byte descriptors (one dword per thread and tile for the
+// train side, each wave's 64 query descriptors once): the expansion bits -> bytes happens here, through a 2 KiB table in LDS
+// (a pre-expanded copy in memory is 8x the bytes; re-reading it per query block and per part made the kernel memory-bound:
+// 163 MB per launch, 21 us with the MFMA pipe 23 % busy).  The words of stage s + 1 are requested before the MFMAs of stage s
+// start and expanded after them, so after the first stage no memory latency is exposed (a workgroup that loaded its whole part
+// up front spent 3.4 of its 8 us waiting, in lockstep with its neighbours: two rounds of that were 24 us).  Three workgroups
+// per CU (register budget): MFMAs of one wave run beside the selection VALU of another.  The 1-D grid is ordered pair-major and
+// dealt to the XCDs in contiguous eighths (placement only, as in k_fast_cells), so the workgroups of a pair share an L2.
+#define MF_STG 3
 #ifdef MF_TRACE
 __device__ unsigned long long g_mf_trace[4 * 4096];
 extern "C" int orbm_debug_mf_trace(unsigned long long *out) { return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_mf_trace), sizeof(g_mf_trace)); }
@@ -89,7 +90,8 @@ __global__ __launch_bounds__(256, 3) void k_best2_mfma(const uint8_t *__restrict
                                                        long long qstride, long long tstride, int cap_q, int cap_t, int out_stride,
                                                        uint2 *__restrict__ part, int nbx, int S, int nbatch, int total)
 {
-    __shared__ uint4 lds[MF_MAXT * 512];            // the split's train tiles as operand bytes (32 descriptors x 256 B = 8 KiB each)
+    __shared__ uint4 lds[2][MF_STG * 512];          // two stages of train tiles as operand bytes (32 descriptors x 256 B = 8 KiB per tile)
+    __shared__ uint2 lut[256];                      // 8 descriptor bits -> 8 operand bytes
     const int lb = (int)(blockIdx.x & 7u) * (int)(gridDim.x >> 3) + (int)(blockIdx.x >> 3);
     if (lb >= total) return;
     MF_STAMP(0);
@@ -97,20 +99,21 @@ __global__ __launch_bounds__(256, 3) void k_best2_mfma(const uint8_t *__restrict
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int qb0 = (bx * 4 + wave) * MF_QB;
     const uint8_t *Q = q + (long long)b * qstride, *T = t + (long long)b * tstride;
-    // All loads first, and none of them waits for another: the descriptor loads go by the CAPACITY of the arrays (rows up to
-    // cap_q / cap_t are allocated, whatever the counts say) while the counts themselves are still on their way; what lies beyond
-    // the counts is masked afterwards.  (Counts first, then addresses, then data was two dependent round trips to memory,
-    // ~2 us of a workgroup's ~8.)  The split geometry comes from cap_t for the same reason.
-    const int ttiles_cap = (cap_t + 31) >> 5, per = min((ttiles_cap + S - 1) / S, MF_MAXT);   // the host picks S with ceil(tiles / S) <= MF_MAXT
+    // The first loads wait for nothing: they go by the CAPACITY of the arrays (rows up to cap_q / cap_t are allocated, whatever
+    // the counts say) while the counts themselves are still on their way; what lies beyond the counts is masked afterwards.
+    const int ttiles_cap = (cap_t + 31) >> 5, per = (ttiles_cap + S - 1) / S;
     const int t0 = bz * per, t1c = min(ttiles_cap, t0 + per);
-    // Train: thread (r = tid & 31, s = tid >> 5) takes word s of descriptor r of every tile of the split.
+    // Train: thread (r = tid & 31, s = tid >> 5) takes word s of descriptor r of every tile of a stage.
     const int tr = tid & 31, ts = tid >> 5;
-    uint32_t tw[MF_MAXT];
+    uint32_t tw[MF_STG];
+    auto load_stage = [&](int tt, int tend) {
 #pragma unroll
-    for (int j = 0; j < MF_MAXT; j++) {
-        const int row = (t0 + j) * 32 + tr;
-        tw[j] = (t0 + j < t1c && row < cap_t) ? *reinterpret_cast<const uint32_t *>(T + (long long)row * 32 + 4 * ts) : 0u;
-    }
+        for (int j = 0; j < MF_STG; j++) {
+            const int row = (tt + j) * 32 + tr;
+            tw[j] = (tt + j < tend && row < cap_t) ? *reinterpret_cast<const uint32_t *>(T + (long long)row * 32 + 4 * ts) : 0u;
+        }
+    };
+    load_stage(t0, t1c);
     // Queries: lane (r, h) of a wave takes descriptor r of each of its MF_QB blocks whole (two 16-byte loads)
     const int qr = lane & 31, qh = lane >> 5;
     uint4 qw[MF_QB][2];
@@ -128,24 +131,34 @@ __global__ __launch_bounds__(256, 3) void k_best2_mfma(const uint8_t *__restrict
     if (bx * 4 * MF_QB >= qblocks) return;                                   // nothing for this workgroup (uniform)
     const bool active = qb0 < qblocks;                                       // wave-uniform; idle waves still help staging
     const int t1 = min((nt + 31) >> 5, t1c);
-    // expand: train words -> LDS (both lane halves of the word's k-step), query words -> the B operand registers
+    {
+        const uint4 e = mf_expand16((uint32_t)tid);            // bytes 0..7 of the result belong to the low byte of the argument
+        lut[tid] = make_uint2(e.x, e.y);
+    }
+    __syncthreads();
+    auto expand16 = [&](uint32_t bits) -> uint4 {
+        const uint2 a = lut[bits & 255u], b2 = lut[(bits >> 8) & 255u];
+        return make_uint4(a.x, a.y, b2.x, b2.y);
+    };
+    auto expand_stage = [&](int tt, int buf) {                 // tw[] -> LDS: both lane halves of the word's k-step
 #pragma unroll
-    for (int j = 0; j < MF_MAXT; j++)
-        if (t0 + j < t1) {
-            const bool valid = (t0 + j) * 32 + tr < nt;     // rows beyond the count: zero operand bytes (they never win: MF_ROW_NONE)
-            lds[j * 512 + ts * 64 + tr] = valid ? mf_expand16(tw[j] & 0xFFFFu) : make_uint4(0, 0, 0, 0);
-            lds[j * 512 + ts * 64 + 32 + tr] = valid ? mf_expand16(tw[j] >> 16) : make_uint4(0, 0, 0, 0);
-        }
+        for (int j = 0; j < MF_STG; j++)
+            if (tt + j < t1) {
+                const bool valid = (tt + j) * 32 + tr < nt;    // rows beyond the count: zero operand bytes (they never win: MF_ROW_NONE)
+                lds[buf][j * 512 + ts * 64 + tr] = valid ? expand16(tw[j] & 0xFFFFu) : make_uint4(0, 0, 0, 0);
+                lds[buf][j * 512 + ts * 64 + 32 + tr] = valid ? expand16(tw[j] >> 16) : make_uint4(0, 0, 0, 0);
+            }
+    };
+    expand_stage(t0, 0);
     v4i bq[MF_QB][8];
 #pragma unroll
     for (int u = 0; u < MF_QB; u++) {
         const uint32_t w8[8] = {qw[u][0].x, qw[u][0].y, qw[u][0].z, qw[u][0].w, qw[u][1].x, qw[u][1].y, qw[u][1].z, qw[u][1].w};
 #pragma unroll
-        for (int s = 0; s < 8; s++) bq[u][s] = __builtin_bit_cast(v4i, mf_expand16((w8[s] >> (16 * qh)) & 0xFFFFu));
+        for (int s = 0; s < 8; s++) bq[u][s] = __builtin_bit_cast(v4i, expand16((w8[s] >> (16 * qh)) & 0xFFFFu));
     }
     __syncthreads();
     MF_STAMP(1);
-    if (!active) return;
 
     int ba[MF_QB], sa[MF_QB];
     uint32_t bk[MF_QB], sk[MF_QB];
@@ -153,42 +166,57 @@ __global__ __launch_bounds__(256, 3) void k_best2_mfma(const uint8_t *__restrict
     for (int u = 0; u < MF_QB; u++) { ba[u] = sa[u] = MF_ACC_NONE; bk[u] = sk[u] = MF_KEY_NONE; }
     const int h4 = 4 * (lane >> 5);
     int c0 = (t0 * 32) & ~(MF_CHUNK - 1);
-    for (int tt = t0; tt < t1; tt++) {
-        const int base = tt * 32;
-        if ((base & ~(MF_CHUNK - 1)) != c0) {       // next index chunk: bank the finished one
+    int buf = 0;
+    for (int tt = t0; tt < t1; tt += MF_STG) {
+        const bool more = tt + MF_STG < t1;
+        if (more) load_stage(tt + MF_STG, t1);                  // in flight during this stage's MFMAs
+        if (active) {
 #pragma unroll
-            for (int u = 0; u < MF_QB; u++) mf_fold(ba[u], sa[u], bk[u], sk[u], c0);
-            c0 = base & ~(MF_CHUNK - 1);
-        }
-        v16i init;
-        const int top = c0 - base - h4;             // -(index of row 0 of this lane's half) relative to the chunk
+            for (int j = 0; j < MF_STG; j++) {
+                if (tt + j >= t1) break;
+                const int base = (tt + j) * 32;
+                if ((base & ~(MF_CHUNK - 1)) != c0) {           // next index chunk: bank the finished one
 #pragma unroll
-        for (int r = 0; r < 16; r++) init[r] = top - ((r & 3) + 8 * (r >> 2));
-        if (base + 32 > nt) {                       // last, partial tile: rows beyond the train count never win
+                    for (int u = 0; u < MF_QB; u++) mf_fold(ba[u], sa[u], bk[u], sk[u], c0);
+                    c0 = base & ~(MF_CHUNK - 1);
+                }
+                v16i init;
+                const int top = c0 - base - h4;                 // -(index of row 0 of this lane's half) relative to the chunk
 #pragma unroll
-            for (int r = 0; r < 16; r++)
-                if (base + h4 + (r & 3) + 8 * (r >> 2) >= nt) init[r] = MF_ROW_NONE;
-        }
-        const uint4 *A = &lds[(tt - t0) * 512];
-        v16i acc[MF_QB];
-        const v4i a0 = __builtin_bit_cast(v4i, A[lane]);
+                for (int r = 0; r < 16; r++) init[r] = top - ((r & 3) + 8 * (r >> 2));
+                if (base + 32 > nt) {                           // last, partial tile: rows beyond the train count never win
 #pragma unroll
-        for (int u = 0; u < MF_QB; u++) acc[u] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a0, bq[u][0], init, 0, 0, 0);
+                    for (int r = 0; r < 16; r++)
+                        if (base + h4 + (r & 3) + 8 * (r >> 2) >= nt) init[r] = MF_ROW_NONE;
+                }
+                const uint4 *A = &lds[buf][j * 512];
+                v16i acc[MF_QB];
+                const v4i a0 = __builtin_bit_cast(v4i, A[lane]);
 #pragma unroll
-        for (int s = 1; s < 8; s++) {
-            const v4i a = __builtin_bit_cast(v4i, A[s * 64 + lane]);
+                for (int u = 0; u < MF_QB; u++) acc[u] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a0, bq[u][0], init, 0, 0, 0);
 #pragma unroll
-            for (int u = 0; u < MF_QB; u++) acc[u] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a, bq[u][s], acc[u], 0, 0, 0);
-        }
+                for (int s = 1; s < 8; s++) {
+                    const v4i a = __builtin_bit_cast(v4i, A[s * 64 + lane]);
 #pragma unroll
-        for (int u = 0; u < MF_QB; u++)
+                    for (int u = 0; u < MF_QB; u++) acc[u] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a, bq[u][s], acc[u], 0, 0, 0);
+                }
 #pragma unroll
-            for (int r = 0; r < 16; r++) {
-                const int x = acc[u][r];
-                sa[u] = mf_med3i(ba[u], sa[u], x);               // second largest of {ba >= sa, x}
-                ba[u] = max(ba[u], x);
+                for (int u = 0; u < MF_QB; u++)
+#pragma unroll
+                    for (int r = 0; r < 16; r++) {
+                        const int x = acc[u][r];
+                        sa[u] = mf_med3i(ba[u], sa[u], x);       // second largest of {ba >= sa, x}
+                        ba[u] = max(ba[u], x);
+                    }
             }
+        }
+        if (more) {
+            expand_stage(tt + MF_STG, buf ^ 1);                 // nobody reads that buffer: its stage was finished before the last barrier
+            __syncthreads();
+        }
+        buf ^= 1;
     }
+    if (!active) return;
 #pragma unroll
     for (int u = 0; u < MF_QB; u++) {
         mf_fold(ba[u], sa[u], bk[u], sk[u], c0);
@@ -205,13 +233,13 @@ __global__ __launch_bounds__(256, 3) void k_best2_mfma(const uint8_t *__restrict
 
 int orbm_mfma_splits(int nq_cap, int nt_cap, int nbatch)
 {
-    // a split is at most MF_MAXT train tiles (it has to fit the workgroup's LDS); beyond that, enough workgroups for three per CU
+    // parts of the train range per frame pair: enough workgroups for three per CU (one round), a part not shorter than two stages
     const int ttiles = std::max((nt_cap + 31) >> 5, 1);
-    int S = (ttiles + MF_MAXT - 1) / MF_MAXT;
     const long long wgs = (long long)nbatch * ((((nq_cap + 31) >> 5) + 4 * MF_QB - 1) / (4 * MF_QB));
-    while ((long long)S * wgs < 768 && S < ttiles) S++;
-    if (const char *e = getenv("ORBM_MFMA_SPLITS")) S = std::max(atoi(e), (ttiles + MF_MAXT - 1) / MF_MAXT);   // tuning switch
-    return std::min(S, ttiles);
+    int S = (int)std::max<long long>((768 + wgs - 1) / std::max<long long>(wgs, 1), 1);
+    if (const char *e = getenv("ORBM_MFMA_SPLITS")) S = std::max(atoi(e), 1);   // tuning switch
+    S = std::min(S, std::max(ttiles / (2 * MF_STG), 1));
+    return std::min(S, 64);
 }
 
 // Partials of nbatch dense pairs -> part[S][nbatch][out_stride]; counts per pair from d_nq / d_nt (device) or the fixed values.

@@ -23,7 +23,7 @@ out = {"calibration": {"bytes_streamed": 1 << 30, "FETCH_SIZE_4B_loads_KB": f4, 
 ff = out["calibration"]["fetch_factor_4B"] or 1.0
 wf = out["calibration"]["write_factor_4B"] or 1.0
 fetch, write = load("bench_fetch"), load("bench_write")
-stage = {"pyramid": "k_resize", "fast": "k_fast_cells", "quadtree": "k_octree", "describe": "k_describe", "match": "k_best2_dense"}
+stage = {"pyramid": "k_resize", "fast": "k_fast_cells", "quadtree": "k_octree", "describe": "k_describe", "match": "k_best2_"}
 for st, pat in stage.items():
     fs = [sum(v) / len(v) * (1 if "resize" not in k else 1) for (k, c), v in fetch.items() if pat in k and c == "FETCH_SIZE"]
     ws = [sum(v) / len(v) for (k, c), v in write.items() if pat in k and c == "WRITE_SIZE"]
