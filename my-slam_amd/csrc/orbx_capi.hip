@@ -819,7 +819,8 @@ extern "C" int orbx_extract_batch(orbx_extractor *h, const uint8_t *images, int 
     // chunk boundaries: a half-size first chunk (the pipeline starts sooner) and a half-size last one (the tail that nothing hides
     // is shorter) around full-size ones
     std::vector<int> cut(1, 0);
-    if (nframes >= 3 * chunk && chunk >= 2) {
+    static const bool equal_chunks = getenv("ORBX_BATCH_EQUAL") != nullptr;   // A/B switch
+    if (nframes >= 3 * chunk && chunk >= 2 && !equal_chunks) {
         cut.push_back(chunk / 2);
         while (nframes - cut.back() > chunk + chunk / 2) cut.push_back(cut.back() + chunk);
         if (nframes - cut.back() > chunk / 2) cut.push_back(nframes - chunk / 2);
