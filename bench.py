@@ -38,6 +38,7 @@ def parse_args(argv=None):
     ap.add_argument("--batch", type=int, default=64, help="frames per GPU per step (weak) / frames in total (strong)")
     ap.add_argument("--scaling", choices=("weak", "strong"), default="weak")
     ap.add_argument("--subbatches", type=int, default=0, help="0 = library default")
+    ap.add_argument("--step-graph", type=int, default=-1, help="1: one HIP graph launch per step (N = 1); 0: kernel by kernel; -1: default (kernel by kernel; measured equal)")
     ap.add_argument("--no-match", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-pipelined", action="store_true", help="skip the extra two-stream / HIP-graph throughput pass")
@@ -416,6 +417,25 @@ def main():
     torch.cuda.synchronize()
     if int(path.status.abs().sum().item()) != 0:
         raise SystemExit("device status nonzero: %s" % path.status.tolist())
+    # One HIP graph launch per step (N = 1): the step's launches -- with --subbatches > 1 two or more concurrent branches, whose
+    # latency-bound kernels (resize chain, quadtree, acceptance) run beside the VALU-bound ones of the other branch -- are captured
+    # once and replayed; issued kernel by kernel the host needs ~5 us per launch.
+    step_graph = None
+    use_graph = args.step_graph == 1 or (args.step_graph < 0 and world == 1 and os.environ.get("ORBX_BENCH_STEP_GRAPH", "0") == "1")
+    if use_graph and world == 1:
+        step_graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(step_graph, stream=stream):
+            path.step(0)
+        torch.cuda.set_stream(stream)
+        plain_step = step
+
+        def step():
+            step_graph.replay()
+        for _ in range(3):
+            step()
+        torch.cuda.synchronize()
+        if int(path.status.abs().sum().item()) != 0:
+            raise SystemExit("device status nonzero after graph replay: %s" % path.status.tolist())
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
@@ -549,6 +569,7 @@ def main():
             "unit": "keypoints/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms, 4), "higher_is_better": True, "scaling": args.scaling,
+            "launch": ("one HIP graph per step" if step_graph is not None else "kernel by kernel") + (", %d concurrent sub-batches" % args.subbatches if args.subbatches > 1 else ""),
             "vs_baseline": None, "dtype": "u8", "data": "synthetic",
             "frames_per_s": round(total / (elapsed / args.steps), 1),
             "timed_region_s": round(elapsed, 5),
