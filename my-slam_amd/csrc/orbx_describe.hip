@@ -201,6 +201,31 @@ struct __attribute__((aligned(16))) DescLds {
     uint32_t P[DW_P_STRIDE * DW_P_ROWS];        // 3520 B
 };
 
+// a wave-uniform pointer pinned to scalar registers (keeps "scalar base + 32-bit lane offset" from being re-associated into
+// 64-bit vector arithmetic)
+typedef const __attribute__((address_space(1))) uint8_t *gptr_u8;   // explicitly global: the integer round trip would leave a flat pointer
+__device__ __forceinline__ gptr_u8 scalar_ptr(const uint8_t *p)
+{
+    const uint64_t b = reinterpret_cast<uint64_t>(p);
+    const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)b), hi = __builtin_amdgcn_readfirstlane((uint32_t)(b >> 32));
+    return (gptr_u8)(((uint64_t)hi << 32) | lo);
+}
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+typedef u32x2 __attribute__((aligned(4))) U2a4;   // two dwords at a 4-byte aligned address (global_load_dwordx2)
+
+// sum over the 64 lanes in six DPP additions (quad swaps, half-row and row mirrors, row broadcasts); every lane of the
+// result is the same scalar
+__device__ __forceinline__ int wave_sum_dpp(int v)
+{
+    v += __builtin_amdgcn_update_dpp(0, v, 0xB1, 0xf, 0xf, true);     // quad_perm:[1,0,3,2]
+    v += __builtin_amdgcn_update_dpp(0, v, 0x4E, 0xf, 0xf, true);     // quad_perm:[2,3,0,1]
+    v += __builtin_amdgcn_update_dpp(0, v, 0x141, 0xf, 0xf, true);    // row_half_mirror
+    v += __builtin_amdgcn_update_dpp(0, v, 0x140, 0xf, 0xf, true);    // row_mirror: every lane holds its row's sum
+    v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xa, 0xf, false);   // row_bcast:15 into rows 1 and 3
+    v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xc, 0xf, false);   // row_bcast:31 into rows 2 and 3
+    return __builtin_amdgcn_readlane(v, 63);
+}
+
 #define DSYNC()                                                \
     do {                                                       \
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); \
@@ -274,34 +299,37 @@ __global__ __launch_bounds__(256) void k_describe(
     const bool fast = (x0 >= 0) && (y0 >= 0) && (y + 21 < L.h) && (x + 21 < L.w) &&   // no reflection needed
                       (x + 27 < row_bytes);                                            // dword over-read stays in the row
     if (fast) {
-        const int rr = lane / 12, d = lane - rr * 12;     // 5 rows per pass, 12 dwords per row
+        // 5 rows per pass, 12 lanes per row; lane d < 11 of a row fetches dwords d and d + 1 of the row segment in one
+        // 8-byte load and funnel-shifts its own output dword out of them (no cross-lane traffic).
+        const int rr = lane / 12, d = lane - rr * 12;
         const int step5 = 5 * L.stride;
-        uint32_t gv[9], xo[9];
-        if (l != 0 || l0_aligned) {   // rows start on a dword: one shift for the whole tile
-            // byte offsets inside one frame fit 31 bits; one 24-bit multiply per lane, the row steps are scalar
-            const uint8_t *src = img + (__mul24(y0 + rr, L.stride) + (x0 & ~3) + 4 * d);
+        if (lane < 60 && d < 11) {
+            uint32_t *dst = reinterpret_cast<uint32_t *>(&S.raw[rr * DW_RAW_STRIDE + 4 * d]);
+            U2a4 gv[9];
+            if (l != 0 || l0_aligned) {   // rows start on a dword: one shift for the whole tile
+                // byte offsets inside one frame fit 31 bits; one 24-bit multiply per lane, the row steps are scalar
+                // (scalar row base) + (32-bit unsigned lane offset): the global_load saddr form, no 64-bit vector arithmetic
+                const uint32_t voff = (uint32_t)(__mul24(y0 + rr, L.stride) + (x0 & ~3) + 4 * d);
+                const uint32_t xo = (uint32_t)x0 & 3u;
 #pragma unroll
-            for (int p = 0; p < 9; p++) {
-                const int r = p * 5 + rr;
-                xo[p] = (uint32_t)x0 & 3u;
-                gv[p] = (lane < 60 && r < 43) ? *reinterpret_cast<const uint32_t *>(src + p * step5) : 0u;
+                for (int p = 0; p < 8; p++) gv[p] = *(const __attribute__((address_space(1))) U2a4 *)(scalar_ptr(img + (long long)(p * step5)) + voff);
+                if (rr < 3) gv[8] = *(const __attribute__((address_space(1))) U2a4 *)(scalar_ptr(img + (long long)(8 * step5)) + voff);
+#pragma unroll
+                for (int p = 0; p < 8; p++) dst[p * (5 * DW_RAW_STRIDE / 4)] = __builtin_amdgcn_alignbyte(gv[p].y, gv[p].x, xo);
+                if (rr < 3) dst[8 * (5 * DW_RAW_STRIDE / 4)] = __builtin_amdgcn_alignbyte(gv[8].y, gv[8].x, xo);
+            } else {                      // caller-owned level 0 with an odd pitch: the shift differs from row to row
+                const uint8_t *b0 = img + (__mul24(y0 + rr, L.stride) + x0) + 4 * d;
+                uint32_t xo[9];
+#pragma unroll
+                for (int p = 0; p < 9; p++) {
+                    const uint8_t *pa = b0 + p * step5;
+                    xo[p] = (uint32_t)reinterpret_cast<uintptr_t>(pa) & 3u;
+                    if (p < 8 || rr < 3) gv[p] = *reinterpret_cast<const U2a4 *>(pa - xo[p]);
+                }
+#pragma unroll
+                for (int p = 0; p < 9; p++)
+                    if (p < 8 || rr < 3) dst[p * (5 * DW_RAW_STRIDE / 4)] = __builtin_amdgcn_alignbyte(gv[p].y, gv[p].x, xo[p]);
             }
-        } else {                      // caller-owned level 0 with an odd pitch: the shift differs from row to row
-            const uintptr_t b0 = reinterpret_cast<uintptr_t>(img + (__mul24(y0 + rr, L.stride) + x0));
-#pragma unroll
-            for (int p = 0; p < 9; p++) {
-                const int r = p * 5 + rr;
-                const uintptr_t pa = b0 + (uintptr_t)(p * step5);
-                xo[p] = (uint32_t)pa & 3u;
-                gv[p] = (lane < 60 && r < 43) ? reinterpret_cast<const uint32_t *>(pa & ~(uintptr_t)3)[d] : 0u;
-            }
-        }
-#pragma unroll
-        for (int p = 0; p < 9; p++) {
-            const uint32_t hi = __shfl_down(gv[p], 1);
-            const uint32_t v = __builtin_amdgcn_alignbyte(hi, gv[p], xo[p]);
-            const int r = p * 5 + rr;
-            if (lane < 60 && r < 43 && d < 11) *reinterpret_cast<uint32_t *>(&S.raw[r * DW_RAW_STRIDE + 4 * d]) = v;
         }
     } else {   // tile crosses the image border (reflect-101): byte path
         for (int i = lane; i < DESC_RAW * DESC_RAW; i += 64) {
@@ -327,11 +355,8 @@ __global__ __launch_bounds__(256) void k_describe(
             m10 += sA - 32 * sB;
             m01 += __mul24((int)e.w, sB);
         }
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) {
-            m10 += __shfl_xor(m10, o);
-            m01 += __shfl_xor(m01, o);
-        }
+        m10 = wave_sum_dpp(m10);
+        m01 = wave_sum_dpp(m01);
     }
     const float angle = fast_atan2_deg((float)m01, (float)m10);
 
@@ -366,12 +391,19 @@ __global__ __launch_bounds__(256) void k_describe(
             ROW4(b0, b1, b2, rb0, rb1, rb2, rb3)
 #undef ROW4
 #undef DOT4
-            o[0] = ra0 | (rb0 << 16); o[1] = ra1 | (rb1 << 16); o[2] = ra2 | (rb2 << 16); o[3] = ra3 | (rb3 << 16);
+            // (row a | row b << 16), every sum <= 65535: one byte permute per output
+            o[0] = __builtin_amdgcn_perm(rb0, ra0, 0x05040100u); o[1] = __builtin_amdgcn_perm(rb1, ra1, 0x05040100u);
+            o[2] = __builtin_amdgcn_perm(rb2, ra2, 0x05040100u); o[3] = __builtin_amdgcn_perm(rb3, ra3, 0x05040100u);
             *reinterpret_cast<uint4 *>(&S.P[te >> 16]) = make_uint4(o[0], o[1], o[2], o[3]);
         }
     }
     DSYNC();
     ORBX_TRACE_STAMP(2);
+
+    // this lane's sample pairs for the descriptor (bits lane, lane + 64, lane + 128, lane + 192): in flight during the column pass
+    float4 pf[4];
+#pragma unroll
+    for (int j = 0; j < 4; j++) pf[j] = c_pat_f[j * 64 + lane];
 
     // ---- column pass: lane = (column pair, block of row pairs); 4 x dot2 per output ----
     uint8_t *bl = S.raw;   // raw is dead from here on
@@ -392,28 +424,30 @@ __global__ __launch_bounds__(256) void k_describe(
 #pragma unroll
                 for (int j = 0; j < 4; j++) w[j] = *reinterpret_cast<const uint2 *>(pin + j * DW_P_STRIDE);
 #define D2(A, K, ACC) __builtin_amdgcn_udot2(__builtin_bit_cast(us2, (A)), __builtin_bit_cast(us2, (uint32_t)(K)), (ACC), false)
-                const uint32_t e0 = D2(w[0].x, K01, D2(w[1].x, K23, D2(w[2].x, K45, D2(w[3].x, K6_, 0u))));
-                const uint32_t e1 = D2(w[0].y, K01, D2(w[1].y, K23, D2(w[2].y, K45, D2(w[3].y, K6_, 0u))));
-                const uint32_t o0 = D2(w[0].x, K_0, D2(w[1].x, K12, D2(w[2].x, K34, D2(w[3].x, K56, 0u))));
-                const uint32_t o1 = D2(w[0].y, K_0, D2(w[1].y, K12, D2(w[2].y, K34, D2(w[3].y, K56, 0u))));
+                // the rounding constant rides in the accumulator: every sum below is (exact sum + 32768) <= 0x01017FFF
+                const uint32_t e0 = D2(w[0].x, K01, D2(w[1].x, K23, D2(w[2].x, K45, D2(w[3].x, K6_, 32768u))));
+                const uint32_t e1 = D2(w[0].y, K01, D2(w[1].y, K23, D2(w[2].y, K45, D2(w[3].y, K6_, 32768u))));
+                const uint32_t o0 = D2(w[0].x, K_0, D2(w[1].x, K12, D2(w[2].x, K34, D2(w[3].x, K56, 32768u))));
+                const uint32_t o1 = D2(w[0].y, K_0, D2(w[1].y, K12, D2(w[2].y, K34, D2(w[3].y, K56, 32768u))));
 #undef D2
-                const uint32_t s4[4] = {e0, e1, o0, o1};
-                uint32_t v4[4];
-                if (simd_cols == 0) {   // wave-uniform: OpenCV portable C path, (sum + 32768) >> 16 saturated
+                // (sum >> 16) of two neighbouring outputs as one u16 pair (a byte permute); saturation to 255 (a sum of bright
+                // pixels reaches 257: the taps add up to 257) and the packing into two bytes are one v_sat_pk_u8_i16
+                uint32_t pe = __builtin_amdgcn_perm(e1, e0, 0x07060302u), po = __builtin_amdgcn_perm(o1, o0, 0x07060302u);
+                if (simd_cols != 0) {   // wave-uniform; x86 SSE2 path for columns < simd_cols: an exact .5 tie rounds to even
+                    const uint32_t s4[4] = {e0, e1, o0, o1};
+                    uint32_t dec[4];
 #pragma unroll
-                    for (int z = 0; z < 4; z++) v4[z] = min((s4[z] + 32768u) >> 16, 255u);
-                } else {                // x86 SSE2 path for columns < simd_cols: an exact .5 tie rounds to even
-#pragma unroll
-                    for (int z = 0; z < 4; z++) {
-                        uint32_t v = (s4[z] + 32768u) >> 16;
-                        const bool tie_to_even = (x - DESC_R + c + (z & 1) < simd_cols) && ((s4[z] & 0xFFFFu) == 0x8000u) && (v & 1u);
-                        v -= tie_to_even ? 1u : 0u;
-                        v4[z] = min(v, 255u);
-                    }
+                    for (int z = 0; z < 4; z++)
+                        dec[z] = ((x - DESC_R + c + (z & 1) < simd_cols) && ((s4[z] & 0xFFFFu) == 0u) && ((s4[z] >> 16) & 1u)) ? 1u : 0u;
+                    pe -= dec[0] | (dec[1] << 16);   // a decremented value is odd, hence >= 1: no borrow between the halves
+                    po -= dec[2] | (dec[3] << 16);
                 }
-                *reinterpret_cast<uint16_t *>(pout) = (uint16_t)(v4[0] | (v4[1] << 8));
-                if (te & (1u << 27))
-                    *reinterpret_cast<uint16_t *>(pout + DW_BL_STRIDE) = (uint16_t)(v4[2] | (v4[3] << 8));
+                uint32_t be, bo;
+                asm("v_sat_pk_u8_i16 %0, %1" : "=v"(be) : "v"(pe));
+                asm("v_sat_pk_u8_i16 %0, %1" : "=v"(bo) : "v"(po));
+                *reinterpret_cast<uint16_t *>(pout) = (uint16_t)be;
+                // the last row pair has no second row: its store lands in row 37 of the 44-row area, which nothing reads
+                *reinterpret_cast<uint16_t *>(pout + DW_BL_STRIDE) = (uint16_t)bo;
             }
         }
     }
@@ -425,9 +459,6 @@ __global__ __launch_bounds__(256) void k_describe(
     float a, b;
     sincos_cr(__fmul_rn(angle, factorPI), &a, &b);
     unsigned long long bits[4];
-    float4 pf[4];
-#pragma unroll
-    for (int j = 0; j < 4; j++) pf[j] = c_pat_f[j * 64 + lane];   // bits lane, lane + 64, lane + 128, lane + 192
     // Both samples of a pair in one packed-fp32 lane pair (v_pk_mul_f32 / v_pk_add_f32: the same IEEE operations, two per
     // instruction; no FMA is formed, the file is built with -ffp-contract=off).  cvRound = round-half-even = adding
     // 1.5 * 2^23: the integer then sits in the low mantissa bits (|value| <= 19), so index = mad24(ri, 40, qi) - const
