@@ -492,6 +492,7 @@ static int ensure_plan(orbx_extractor *h, int W, int H)
         const OrbxLevel &S = P.lv[l - 1];
         const size_t ex = align_up((size_t)L.w + 4, 4), ey = align_up((size_t)L.h + 4, 4);
         plan_resize(S.w, S.h, L.w, L.h, &ti[e], &ts[e], &ti[e + ex], &ts[e + ex], &h->area2[l]);
+        for (size_t dy = (size_t)L.h; dy < ey; dy++) { ti[e + ex + dy] = ti[e + ex + L.h - 1]; ts[e + ex + dy] = ts[e + ex + L.h - 1]; }   // k_resize_linear_4x4 reads rows in fours
         yofs_at[l] = e + ex;
         h->tabs[l].xofs = h->d_tab_i + e; h->tabs[l].alpha = h->d_tab_s + e;
         h->tabs[l].yofs = h->d_tab_i + e + ex; h->tabs[l].beta = h->d_tab_s + e + ex;

@@ -99,11 +99,18 @@ __global__ __launch_bounds__(256) void k_resize_linear_4x4(
     const uint32_t endoff = CHECK ? (uint32_t)(src_end - S) : 0u;   // only meaningful (and only used) for the last frame
     int b0v[4], b1v[4];
     uint32_t sh8[4][2], wv[4][2][3];
+    // the row tables of the block's four rows in two 16-byte loads (y4 is a multiple of 4; the planner pads both tables to a
+    // multiple of 4 rows with copies of the last row, so no clamp is needed here)
+    const int4 syv = *reinterpret_cast<const int4 *>(tab.yofs + y4);
+    const uint4 bwv = *reinterpret_cast<const uint4 *>(tab.beta + y4);
+    const int sy4[4] = {syv.x, syv.y, syv.z, syv.w};
+    const uint32_t bw4[4] = {bwv.x, bwv.y, bwv.z, bwv.w};
+    typedef uint32_t u32x3 __attribute__((ext_vector_type(3)));
+    typedef u32x3 __attribute__((aligned(4))) U3a4;   // three dwords at a 4-byte aligned address: one global_load_dwordx3
 #pragma unroll
     for (int r = 0; r < 4; r++) {
-        const int y = min(y4 + r, dh - 1);
-        const int sy = tab.yofs[y];
-        const uint32_t bw = *reinterpret_cast<const uint32_t *>(tab.beta + y);
+        const int sy = sy4[r];
+        const uint32_t bw = bw4[r];
         b0v[r] = (int)(short)(bw & 0xFFFFu);
         b1v[r] = (int)(short)(bw >> 16);
         const int sy0 = min(max(sy, 0), sh - 1), sy1 = min(max(sy + 1, 0), sh - 1);
@@ -112,13 +119,14 @@ __global__ __launch_bounds__(256) void k_resize_linear_4x4(
             const uint32_t off = (uint32_t)(__mul24(rr ? sy1 : sy0, sstride) + base);   // 24-bit multiply is full rate
             sh8[r][rr] = (s_lo + off) & 3u;
             const uint32_t offa = off - sh8[r][rr];
-            const uint32_t *q = reinterpret_cast<const uint32_t *>(S + offa);
             if (CHECK && blockIdx.z == gridDim.z - 1) {   // only the last frame can end at the end of the caller's buffer
+                const uint32_t *q = reinterpret_cast<const uint32_t *>(S + offa);
                 wv[r][rr][0] = q[0];
                 wv[r][rr][1] = (offa + 8u <= endoff) ? q[1] : 0u;
                 wv[r][rr][2] = (offa + 12u <= endoff) ? q[2] : 0u;
             } else {
-                wv[r][rr][0] = q[0]; wv[r][rr][1] = q[1]; wv[r][rr][2] = q[2];
+                const U3a4 q = *reinterpret_cast<const U3a4 *>(S + offa);
+                wv[r][rr][0] = q.x; wv[r][rr][1] = q.y; wv[r][rr][2] = q.z;
             }
         }
     }
@@ -147,8 +155,11 @@ __global__ __launch_bounds__(256) void k_resize_linear_4x4(
         }
         uint8_t *Dr = D + (uint32_t)(__mul24(y, dstride) + x4);
         if (x4 + 3 < dw) *reinterpret_cast<uint32_t *>(Dr) = out;
-        else
-            for (int i = 0; x4 + i < dw; i++) Dr[i] = (uint8_t)(out >> (8 * i));
+        else {   // the last block of a row: 1..3 pixels (three predicated byte stores; a loop here gets vectorised into a mess)
+            Dr[0] = (uint8_t)out;
+            if (x4 + 1 < dw) Dr[1] = (uint8_t)(out >> 8);
+            if (x4 + 2 < dw) Dr[2] = (uint8_t)(out >> 16);
+        }
     }
 }
 
