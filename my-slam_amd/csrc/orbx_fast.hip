@@ -23,12 +23,6 @@
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); \
     } while (0)
 
-#ifndef FAST_REJECT_POINTS
-#define FAST_REJECT_POINTS 4   // stage-1 reject on 4 or 8 circle points (both necessary conditions; results identical)
-#endif
-#ifndef FAST_QUEUE_ROWMAJOR
-#define FAST_QUEUE_ROWMAJOR 1
-#endif
 #define FAST_PADL 4      // left pad (bytes) of every tile row so that dword g-1 exists for every group
 #define FAST_CLIST 224   // corners listed per cell before NMS falls back to scanning the whole score map
 
@@ -46,34 +40,19 @@ struct FastLds {
 typedef unsigned short us2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ us2 as_us2(uint32_t v) { return __builtin_bit_cast(us2, v); }
 __device__ __forceinline__ uint32_t as_u32(us2 v) { return __builtin_bit_cast(uint32_t, v); }
-__device__ __forceinline__ us2 lo2(uint32_t d) { return as_us2(__builtin_amdgcn_perm(0u, d, 0x0c010c00u)); }   // bytes 0,1 -> u16 x2
-__device__ __forceinline__ us2 hi2(uint32_t d) { return as_us2(__builtin_amdgcn_perm(0u, d, 0x0c030c02u)); }   // bytes 2,3 -> u16 x2
 
-// 8-point reject for two pixels at once (u16 lanes).  A 9-arc holds one pixel of each opposite pair
-// and all its pixels are on one side, so a corner needs  v - t > max_k min(p_k, p_k+8)  (all four pairs
-// have a darker member) or  v + t < min_k max(p_k, p_k+8).  Returns non-zero u16 lanes where it holds.
-__device__ __forceinline__ uint32_t reject8(us2 c, us2 t, us2 a0, us2 a8, us2 a4, us2 a12, us2 a2, us2 a10, us2 a6, us2 a14)
-{
-    const us2 mlo = __builtin_elementwise_max(__builtin_elementwise_max(__builtin_elementwise_min(a0, a8), __builtin_elementwise_min(a4, a12)),
-                                              __builtin_elementwise_max(__builtin_elementwise_min(a2, a10), __builtin_elementwise_min(a6, a14)));
-    const us2 mhi = __builtin_elementwise_min(__builtin_elementwise_min(__builtin_elementwise_max(a0, a8), __builtin_elementwise_max(a4, a12)),
-                                              __builtin_elementwise_min(__builtin_elementwise_max(a2, a10), __builtin_elementwise_max(a6, a14)));
-    const us2 dark = __builtin_elementwise_sub_sat(__builtin_elementwise_sub_sat(c, t), mlo);
-    const us2 bright = __builtin_elementwise_sub_sat(mhi, c + t);
-    return as_u32(dark) | as_u32(bright);
-}
-
-typedef short ss2 __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ ss2 pk(int lo, int hi) { return __builtin_bit_cast(ss2, (uint32_t)(lo & 0xFFFF) | ((uint32_t)hi << 16)); }
-
-// 4-point variant: pairs (0,8) and (4,12) only.  Passes ~20 % more pixels to stage 2 than the 8-point test but
-// costs half of it; measured faster overall on MI355X (the kernel is VALU-bound).
+// Stage-1 reject for two pixels at once (u16 lanes).  A 9-arc holds one pixel of each opposite pair and all its pixels are
+// on one side, so a corner needs  v - t > max_k min(p_k, p_k+8)  (every pair has a darker member) or
+// v + t < min_k max(p_k, p_k+8).  Returns non-zero u16 lanes where it holds.
+// Pairs (0,8) and (4,12) only: testing all four even pairs passes ~20 % fewer pixels to stage 2 but costs twice as much;
+// measured slower overall on MI355X (the kernel is VALU-bound).
+template <bool SCALED>   // SCALED: the values are bytes << 8; c + t can pass 65535 and must saturate (no pixel is brighter than that)
 __device__ __forceinline__ uint32_t reject4(us2 c, us2 t, us2 a0, us2 a8, us2 a4, us2 a12)
 {
     const us2 mlo = __builtin_elementwise_max(__builtin_elementwise_min(a0, a8), __builtin_elementwise_min(a4, a12));
     const us2 mhi = __builtin_elementwise_min(__builtin_elementwise_max(a0, a8), __builtin_elementwise_max(a4, a12));
     const us2 dark = __builtin_elementwise_sub_sat(__builtin_elementwise_sub_sat(c, t), mlo);
-    const us2 bright = __builtin_elementwise_sub_sat(mhi, c + t);
+    const us2 bright = __builtin_elementwise_sub_sat(mhi, SCALED ? __builtin_elementwise_add_sat(c, t) : c + t);
     return as_u32(dark) | as_u32(bright);
 }
 
@@ -82,7 +61,7 @@ __device__ __forceinline__ uint32_t reject4(us2 c, us2 t, us2 a0, us2 a8, us2 a4
 // A pixel is a corner at threshold t  <=>  score >= t, so no separate arc test is needed.
 // The values are small integers (|d| <= 255), exact in fp16, and gfx950 has three-input packed fp16 min/max
 // (v_pk_minimum3_f16 / v_pk_maximum3_f16): a 9-window is min3 of three min3's, so one polarity costs
-// 16 + 16 + 8 instructions instead of the 79 of a two-input tree.  A byte b in a 16-bit half IS the fp16 subnormal
+// 36 instructions (see below) instead of the 79 of a two-input tree.  A byte b in a 16-bit half IS the fp16 subnormal
 // b * 2^-24 (gfx950 kernels run with fp16 subnormals enabled, .amdhsa_float_denorm_mode_16_64 3), differences and
 // min/max of such values are exact, and a non-negative result read back as an integer is the value again: no
 // conversion in either direction.
@@ -112,26 +91,30 @@ __device__ __forceinline__ void fast_stage2(const uint8_t *T0, const uint16_t *q
     d[10] = v - pkh(p[-2 * TS - 2], q[-2 * TS - 2]); d[11] = v - pkh(p[-1 * TS - 3], q[-1 * TS - 3]);
     d[12] = v - pkh(p[-3], q[-3]);                   d[13] = v - pkh(p[1 * TS - 3], q[1 * TS - 3]);
     d[14] = v - pkh(p[2 * TS - 2], q[2 * TS - 2]);   d[15] = v - pkh(p[3 * TS - 1], q[3 * TS - 1]);
+    // With m2[j] = min(d[k], d[k+1]) for odd k = 2 j + 1, the 8-window starting at k is min(m2[j..j+3]); the two 9-arcs that
+    // contain it add d[k-1] or d[k+8], and max(min(a, x), min(a, y)) = min(a, max(x, y)):
+    //   A = max over odd k of min(window_k, max(d[k-1], d[k+8]))        (36 instructions; 40 as min3 of min3 over all 16 arcs)
+    // and the same with min and max exchanged for the bright polarity.
     hh2 A, B;
-    {   // A = max over the 16 arcs of the minimum of their 9 values
-        hh2 m3[16], m9[16];
+    {
+        hh2 m2[8], e[8], r[8];
 #pragma unroll
-        for (int k = 0; k < 16; k++) m3[k] = hmin3(d[k], d[(k + 1) & 15], d[(k + 2) & 15]);
+        for (int j = 0; j < 8; j++) m2[j] = __builtin_elementwise_minimum(d[2 * j + 1], d[(2 * j + 2) & 15]);
 #pragma unroll
-        for (int k = 0; k < 16; k++) m9[k] = hmin3(m3[k], m3[(k + 3) & 15], m3[(k + 6) & 15]);
-        const hh2 a0 = hmax3(m9[0], m9[1], m9[2]), a1 = hmax3(m9[3], m9[4], m9[5]), a2 = hmax3(m9[6], m9[7], m9[8]);
-        const hh2 a3 = hmax3(m9[9], m9[10], m9[11]), a4 = hmax3(m9[12], m9[13], m9[14]);
-        A = hmax3(hmax3(a0, a1, a2), hmax3(a3, a4, m9[15]), a0);
+        for (int j = 0; j < 8; j++) e[j] = __builtin_elementwise_maximum(d[2 * j], d[(2 * j + 9) & 15]);
+#pragma unroll
+        for (int j = 0; j < 8; j++) r[j] = hmin3(hmin3(m2[j], m2[(j + 1) & 7], m2[(j + 2) & 7]), m2[(j + 3) & 7], e[j]);
+        A = hmax3(hmax3(r[0], r[1], r[2]), hmax3(r[3], r[4], r[5]), __builtin_elementwise_maximum(r[6], r[7]));
     }
-    {   // B = min over the arcs of the maximum (the bright polarity, negated below)
-        hh2 m3[16], m9[16];
+    {
+        hh2 m2[8], e[8], r[8];
 #pragma unroll
-        for (int k = 0; k < 16; k++) m3[k] = hmax3(d[k], d[(k + 1) & 15], d[(k + 2) & 15]);
+        for (int j = 0; j < 8; j++) m2[j] = __builtin_elementwise_maximum(d[2 * j + 1], d[(2 * j + 2) & 15]);
 #pragma unroll
-        for (int k = 0; k < 16; k++) m9[k] = hmax3(m3[k], m3[(k + 3) & 15], m3[(k + 6) & 15]);
-        const hh2 b0 = hmin3(m9[0], m9[1], m9[2]), b1 = hmin3(m9[3], m9[4], m9[5]), b2 = hmin3(m9[6], m9[7], m9[8]);
-        const hh2 b3 = hmin3(m9[9], m9[10], m9[11]), b4 = hmin3(m9[12], m9[13], m9[14]);
-        B = hmin3(hmin3(b0, b1, b2), hmin3(b3, b4, m9[15]), b0);
+        for (int j = 0; j < 8; j++) e[j] = __builtin_elementwise_minimum(d[2 * j], d[(2 * j + 9) & 15]);
+#pragma unroll
+        for (int j = 0; j < 8; j++) r[j] = hmax3(hmax3(m2[j], m2[(j + 1) & 7], m2[(j + 2) & 7]), m2[(j + 3) & 7], e[j]);
+        B = hmin3(hmin3(r[0], r[1], r[2]), hmin3(r[3], r[4], r[5]), __builtin_elementwise_minimum(r[6], r[7]));
     }
     const hh2 zero = {(_Float16)0.0f, (_Float16)0.0f};
     const uint32_t scb = __builtin_bit_cast(uint32_t, hmax3(A, -B, zero));   // (score + 1) * 2^-24 per half, clamped at 0
@@ -235,6 +218,7 @@ __global__ __launch_bounds__(FAST_THREADS) void k_fast_cells(OrbxPlan plan, Orbx
     const int ng = (zw + 3) >> 2;
     const uint32_t rcpg = (c_rcp20[ng] + 15u) >> 4;          // (1 << 16) / ng + 1 (or one more): t / ng for t < 1024, ng <= 16
     const int ntask = ng * zh;
+    const int qlast = zw - 4 * (ng - 1);                     // pixels of a zone row's last group that are inside the zone (1..4)
 
     // The reference calls FAST at iniThFAST and, only when that cell yields nothing, again at
     // minThFAST (:811-818).  Same here: the first pass thresholds at iniThFAST; a cell with no NMS
@@ -250,7 +234,7 @@ __global__ __launch_bounds__(FAST_THREADS) void k_fast_cells(OrbxPlan plan, Orbx
         WSYNC();
 
         // ---- stages 1+2.  Stage-1 task = (zone row, dword group): 4 horizontally adjacent pixels ----
-        const us2 tt = as_us2((uint32_t)t_lo * 0x00010001u);
+        const us2 tt = as_us2((uint32_t)t_lo * 0x00010001u), ttO = as_us2((uint32_t)t_lo * 0x01000100u);
         int qn = 0, ncl = 0;
         bool cl_over = false;
 #define DRAIN(CNT)                                                                                                   \
@@ -266,12 +250,18 @@ __global__ __launch_bounds__(FAST_THREADS) void k_fast_cells(OrbxPlan plan, Orbx
         } else cl_over = true;                                                                                       \
     } while (0)
         for (int base = 0; base < ntask; base += 64) {
-            // lanes past the last task redo the last one; their pixels are masked out through zx0
-            const int t = min(base + lane, ntask - 1);
+            // Which pixels of a step count is decided on the scalar unit: lanes past the last task (a bit-field mask) and, in
+            // the last group of a zone row, the pixels past the zone's right edge (qlast of its 4 are inside) -- one vector
+            // compare per step instead of five and a select.  Lanes past the last task compute on whatever LDS holds there.
+            const int t = base + lane;
             const int zy = (int)(__umul24((uint32_t)t, rcpg) >> 16);
-            const int g = g0 + (t - (int)__umul24((uint32_t)zy, (uint32_t)ng));
-            const int zx0 = (base + lane < ntask) ? 4 * g - cb : 1000;   // zone column of byte 0 of this group (>= 0)
-            uint32_t f01, f23;
+            const int gi = t - (int)__umul24((uint32_t)zy, (uint32_t)ng);
+            const int g = g0 + gi;
+            const int zx0 = 4 * gi;                                  // zone column of byte 0 of this group
+            const int nvalid = min(ntask - base, 64);
+            const unsigned long long VALID = nvalid >= 64 ? ~0ull : ((1ull << nvalid) - 1ull);
+            const unsigned long long NOTLAST = ~__builtin_amdgcn_ballot_w64(gi == ng - 1);
+            uint32_t fE, fO;   // non-zero u16 halves = survivors: fE pixels (0, 2), fO pixels (1, 3)
             {
                 const uint32_t *r0 = reinterpret_cast<const uint32_t *>(&S.tile[(zy + 3) * TS]) + g;
                 const uint32_t dD = *(reinterpret_cast<const uint32_t *>(&S.tile[(zy + 6) * TS]) + g);   // pixel 0  (0,+3)
@@ -279,43 +269,33 @@ __global__ __launch_bounds__(FAST_THREADS) void k_fast_cells(OrbxPlan plan, Orbx
                 const uint32_t cL = r0[-1], cC = r0[0], cR = r0[1];
                 const uint32_t d4 = __builtin_amdgcn_alignbyte(cR, cC, 3);    // pixel 4  (+3, 0)
                 const uint32_t d12 = __builtin_amdgcn_alignbyte(cC, cL, 1);   // pixel 12 (-3, 0)
-#if FAST_REJECT_POINTS == 8
-                const uint32_t *rp = reinterpret_cast<const uint32_t *>(&S.tile[(zy + 5) * TS]) + g;
-                const uint32_t *rm = reinterpret_cast<const uint32_t *>(&S.tile[(zy + 1) * TS]) + g;
-                const uint32_t pL = rp[-1], pC = rp[0], pR = rp[1];
-                const uint32_t mL = rm[-1], mC = rm[0], mR = rm[1];
-                const uint32_t d2 = __builtin_amdgcn_alignbyte(pR, pC, 2);    // pixel 2  (+2,+2)
-                const uint32_t d14 = __builtin_amdgcn_alignbyte(pC, pL, 2);   // pixel 14 (-2,+2)
-                const uint32_t d6 = __builtin_amdgcn_alignbyte(mR, mC, 2);    // pixel 6  (+2,-2)
-                const uint32_t d10 = __builtin_amdgcn_alignbyte(mC, mL, 2);   // pixel 10 (-2,-2)
-                f01 = reject8(lo2(cC), tt, lo2(dD), lo2(dU), lo2(d4), lo2(d12), lo2(d2), lo2(d10), lo2(d6), lo2(d14));
-                f23 = reject8(hi2(cC), tt, hi2(dD), hi2(dU), hi2(d4), hi2(d12), hi2(d2), hi2(d10), hi2(d6), hi2(d14));
-#else
-                f01 = reject4(lo2(cC), tt, lo2(dD), lo2(dU), lo2(d4), lo2(d12));
-                f23 = reject4(hi2(cC), tt, hi2(dD), hi2(dU), hi2(d4), hi2(d12));
-#endif
+                // Even bytes (pixels 0 and 2) and odd bytes (pixels 1 and 3, left scaled by 256: order, saturating
+                // differences and the non-zero tests do not care) of a dword are two u16 pairs after ONE full-rate AND each
+                // (a byte permute is a half-rate instruction).
+#define EV(X) as_us2((X) & 0x00FF00FFu)
+#define OD(X) as_us2((X) & 0xFF00FF00u)
+                fE = reject4<false>(EV(cC), tt, EV(dD), EV(dU), EV(d4), EV(d12));
+                fO = reject4<true>(OD(cC), ttO, OD(dD), OD(dU), OD(d4), OD(d12));
+#undef EV
+#undef OD
             }
             // append the survivors of the 4 pixels: four ballots, one queue update (entry order is free)
             // (each ballot is taken straight from a compare and combined on the scalar unit; a ballot of a combined
             // predicate costs two more vector instructions)
-            const bool f0 = (f01 & 0x0000FFFFu) != 0, f1 = (f01 & 0xFFFF0000u) != 0;
-            const bool f2 = (f23 & 0x0000FFFFu) != 0, f3 = (f23 & 0xFFFF0000u) != 0;
-            const bool h0 = zx0 < zw, h1 = zx0 < zw - 1, h2 = zx0 < zw - 2, h3 = zx0 < zw - 3;
-            const bool k0 = f0 && h0, k1 = f1 && h1, k2 = f2 && h2, k3 = f3 && h3;
+            const bool f0 = (fE & 0x0000FFFFu) != 0, f1 = (fO & 0x0000FFFFu) != 0;
+            const bool f2 = (fE & 0xFFFF0000u) != 0, f3 = (fO & 0xFFFF0000u) != 0;
 #define BAL(P) __builtin_amdgcn_ballot_w64(P)
-            const unsigned long long b0 = BAL(f0) & BAL(h0), b1 = BAL(f1) & BAL(h1);
-            const unsigned long long b2 = BAL(f2) & BAL(h2), b3 = BAL(f3) & BAL(h3);
+            const unsigned long long b0 = BAL(f0) & VALID, b1 = BAL(f1) & (qlast > 1 ? VALID : VALID & NOTLAST);
+            const unsigned long long b2 = BAL(f2) & (qlast > 2 ? VALID : VALID & NOTLAST), b3 = BAL(f3) & (qlast > 3 ? VALID : VALID & NOTLAST);
 #undef BAL
+            // the lane's own bit of each (uniform) mask as a select operand: no vector instruction
+            const bool k0 = __builtin_amdgcn_inverse_ballot_w64(b0), k1 = __builtin_amdgcn_inverse_ballot_w64(b1);
+            const bool k2 = __builtin_amdgcn_inverse_ballot_w64(b2), k3 = __builtin_amdgcn_inverse_ballot_w64(b3);
             const int n0 = __popcll(b0), n1 = __popcll(b1), n2 = __popcll(b2);
-#if FAST_QUEUE_ROWMAJOR
             // queue in the zone's row-major pixel order: entry = survivors of lower lanes (all four pixels) + own lower pixels.
             // Neighbouring lanes of stage 2 then gather from neighbouring LDS addresses (bank conflicts: DESIGN.md §4).
             const int e0 = orbx_prefix_cnt(b3, orbx_prefix_cnt(b2, orbx_prefix_cnt(b1, orbx_prefix_cnt(b0, qn))));
             const int e1 = e0 + (k0 ? 1 : 0), e2 = e1 + (k1 ? 1 : 0), e3 = e2 + (k2 ? 1 : 0);
-#else
-            const int e0 = orbx_prefix_cnt(b0, qn), e1 = orbx_prefix_cnt(b1, qn + n0);
-            const int e2 = orbx_prefix_cnt(b2, qn + n0 + n1), e3 = orbx_prefix_cnt(b3, qn + n0 + n1 + n2);
-#endif
             const int pz = (zy << 6) + zx0;          // (zy << 6) | zx for every pixel with 0 <= zx < 64
             S.queue[k0 ? e0 : 383] = (uint16_t)pz;
             S.queue[k1 ? e1 : 383] = (uint16_t)(pz + 1);
