@@ -24,6 +24,20 @@ __device__ __forceinline__ int orbx_prefix_cnt(unsigned long long mask, int base
 {
     return (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, (uint32_t)base));
 }
+// Inclusive prefix sum over the 64 lanes in six DPP additions (row shifts 1, 2, 4, 8, then the row totals carried across with
+// row_bcast:15 / row_bcast:31) -- registers only; __shfl_up() is a ds_bpermute round trip through the LDS unit per step.
+__device__ __forceinline__ int orbx_wave_incl_scan(int v)
+{
+    v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, true);    // row_shr:1, lanes without a source add 0
+    v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xf, 0xf, true);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xf, 0xf, true);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xf, 0xf, true);    // every row of 16 holds its own inclusive scan
+    v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xa, 0xf, false);   // row_bcast:15 -> rows 1 and 3
+    v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xc, 0xf, false);   // row_bcast:31 -> rows 2 and 3
+    return v;
+}
+// value of the previous lane (lane 0: 0): DPP wave_shr:1
+__device__ __forceinline__ int orbx_lane_prev(int v) { return __builtin_amdgcn_update_dpp(0, v, 0x138, 0xf, 0xf, true); }
 #endif
 
 // -DORBX_TRACE: per-phase shader-clock totals summed over all waves of a kernel (tools/dbg/phase_trace.py); slot 7 counts waves.

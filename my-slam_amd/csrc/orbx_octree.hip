@@ -15,40 +15,35 @@
 //     from (x, y): cells row-major, then rows, then columns.
 // The reference's pointer tie-break in the sort (:629,:686) is taken as creation order.
 // -------------------------------------------------------------------------------------------------
+// Exclusive prefix sum over the workgroup, ONE barrier: every wave scans its lanes in registers (DPP), publishes its total, and
+// after the barrier adds up the totals of the waves below it itself (T / 64 <= 16 values, one DPP row scan).  Consecutive calls
+// alternate between two sets of totals (wsum[2][16]), so a wave that is one call ahead never overwrites what a slower wave is
+// still reading: being two calls ahead needs the barrier of the call in between.
 template <int T>
-__device__ __forceinline__ int block_excl_scan(int v, int *total, int *wsum)
+__device__ __forceinline__ int block_excl_scan(int v, int *total, int (*wsum)[16], int &parity)
 {
+    constexpr int NW = T / 64;
+    static_assert(NW <= 16, "one DPP row holds the wave totals");
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    int inc = v;
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-        const int t = __shfl_up(inc, o);
-        if (lane >= o) inc += t;
-    }
-    if (lane == 63) wsum[wave] = inc;
+    const int inc = orbx_wave_incl_scan(v);
+    int *ws = wsum[parity];
+    parity ^= 1;
+    if (lane == 63) ws[wave] = inc;
     __syncthreads();
-    if (wave == 0) {
-        int w = lane < T / 64 ? wsum[lane] : 0;
-        int winc = w;
-#pragma unroll
-        for (int o = 1; o < T / 64; o <<= 1) {
-            const int t = __shfl_up(winc, o);
-            if (lane >= o) winc += t;
-        }
-        if (lane < T / 64) wsum[lane] = winc - w;
-        if (lane == T / 64 - 1) wsum[T / 64] = winc;
-    }
-    __syncthreads();
-    const int res = wsum[wave] + inc - v;
-    *total = wsum[T / 64];
-    __syncthreads();
-    return res;
+    int w = lane < NW ? ws[lane] : 0;
+    w += __builtin_amdgcn_update_dpp(0, w, 0x111, 0xf, 0xf, true);
+    w += __builtin_amdgcn_update_dpp(0, w, 0x112, 0xf, 0xf, true);
+    w += __builtin_amdgcn_update_dpp(0, w, 0x114, 0xf, 0xf, true);
+    w += __builtin_amdgcn_update_dpp(0, w, 0x118, 0xf, 0xf, true);
+    *total = __builtin_amdgcn_readlane(w, NW - 1);
+    const int below = __builtin_amdgcn_readlane(w, wave > 0 ? wave - 1 : 0);
+    return (wave > 0 ? below : 0) + inc - v;
 }
 
 template <int T>
 struct OctShared {
     int m, prevM, arenaN, lastBase, lastC, nAlive, nE, C, nToExpand, phaseB, done, cutoff, err, firstPass;
-    int wsum[T / 64 + 2];
+    int wsum[2][16];
 };
 
 __device__ __forceinline__ void oct_child_box(const OrbxNode &p, int q, OrbxNode &c)
@@ -91,7 +86,7 @@ __device__ unsigned long long g_oct_trace[256];
 __device__ __forceinline__ void wave_count(uint32_t *ctr, int idx)
 {
     const int lane = (int)__lane_id();
-    const int prev = __shfl_up(idx, 1);
+    const int prev = orbx_lane_prev(idx);
     const bool head = lane == 0 || prev != idx;
     const unsigned long long hm = __builtin_amdgcn_ballot_w64(head);
     if (head && idx >= 0) {
@@ -107,7 +102,7 @@ __device__ __forceinline__ void wave_count(uint32_t *ctr, int idx)
 // keys: counted directly (every thread streams the same LDS words: broadcasts) instead of a bitonic sort.
 template <int T>
 __device__ __forceinline__ int oct_assign_slots(OrbxNode *ln, int cntN, bool forward, bool phaseB, uint32_t *slotNode,
-                                                unsigned long long *scratch, OctShared<T> &sh)
+                                                unsigned long long *scratch, OctShared<T> &sh, int &scanp)
 {
     const int tid = threadIdx.x;
     if (!phaseB) {
@@ -120,7 +115,7 @@ __device__ __forceinline__ int oct_assign_slots(OrbxNode *ln, int cntN, bool for
                 alive = ln[cidx].count > 1;
             }
             int tot;
-            const int ex = block_excl_scan<T>(alive, &tot, sh.wsum);
+            const int ex = block_excl_scan<T>(alive, &tot, sh.wsum, scanp);
             if (alive) {
                 slotNode[carry + ex] = (uint32_t)cidx;
                 ln[cidx].slot = carry + ex;
@@ -140,7 +135,7 @@ __device__ __forceinline__ int oct_assign_slots(OrbxNode *ln, int cntN, bool for
         const unsigned long long am = __builtin_amdgcn_ballot_w64(c > 1);
         int wbase = 0;
         if (__lane_id() == 0 && am) wbase = atomicAdd(&sh.nAlive, __popcll(am));
-        wbase = __shfl(wbase, 0);
+        wbase = __builtin_amdgcn_readfirstlane(wbase);
         if (c > 1) keys[orbx_prefix_cnt(am, wbase)] = ((uint32_t)c << 12) | (uint32_t)j;
     }
     __syncthreads();
@@ -251,6 +246,7 @@ __device__ __forceinline__ void oct_body(const OrbxPlan &plan, const OrbxWork &w
     }
     static_assert(KU % 4 == 0, "keys are processed four at a time");
     const int tid = threadIdx.x;
+    int scanp = 0;   // which set of wave totals the next workgroup scan uses (block_excl_scan)
 #ifdef OCT_TRACE
     int tp = 0;
 #endif
@@ -336,7 +332,7 @@ __device__ __forceinline__ void oct_body(const OrbxPlan &plan, const OrbxWork &w
     int depth = 0;                 // depth of the nodes in the window lnA
     bool fast = D > 0;             // the keys still carry their paths (wv = leaf g), not node ids
     // first DivideNode of every splittable root: slots, then the quadrant counts (from the table, or one key loop)
-    int nAlive = oct_assign_slots<T>(lnA, lastC, true, false, slotNode, reinterpret_cast<unsigned long long *>(cn), sh);
+    int nAlive = oct_assign_slots<T>(lnA, lastC, true, false, slotNode, reinterpret_cast<unsigned long long *>(cn), sh, scanp);
     __syncthreads();
     for (int i = tid; i < 4 * nAlive; i += T) cc[i] = 0;
     __syncthreads();
@@ -370,7 +366,7 @@ __device__ __forceinline__ void oct_body(const OrbxPlan &plan, const OrbxWork &w
             int ne = 0;
             if (s < nAlive) ne = (cc[4 * s] > 0) + (cc[4 * s + 1] > 0) + (cc[4 * s + 2] > 0) + (cc[4 * s + 3] > 0);
             int tot;
-            const int ex = block_excl_scan<T>(ne, &tot, sh.wsum);
+            const int ex = block_excl_scan<T>(ne, &tot, sh.wsum, scanp);
             if (s < nAlive) {
                 childBase[s] = carry + ex;
                 if (phaseB && m + carry + ex + ne - (s + 1) >= N) atomicMin(&sh.cutoff, s);
@@ -432,7 +428,7 @@ __device__ __forceinline__ void oct_body(const OrbxPlan &plan, const OrbxWork &w
                 }
             }
             int tot;
-            const int ex = block_excl_scan<T>(keep, &tot, sh.wsum);
+            const int ex = block_excl_scan<T>(keep, &tot, sh.wsum, scanp);
             if (keep) nxt[C + scarry + ex] = id;
             scarry += tot;
         }
@@ -471,7 +467,7 @@ __device__ __forceinline__ void oct_body(const OrbxPlan &plan, const OrbxWork &w
         }
         // not finished: every splittable node was expanded (a phase-B cut-off always finishes), so all live keys move.
         // Slots for the children, then ONE key loop: key -> child, and its quadrant inside that child.
-        const int nAliveNext = oct_assign_slots<T>(lnB, C, false, phaseBnext != 0, slotNode, reinterpret_cast<unsigned long long *>(cn), sh);
+        const int nAliveNext = oct_assign_slots<T>(lnB, C, false, phaseBnext != 0, slotNode, reinterpret_cast<unsigned long long *>(cn), sh, scanp);
         OCT_T(phaseBnext ? 6 : 5);
         for (int i = tid; i < 4 * nAliveNext; i += T) cn[i] = 0;
         __syncthreads();
