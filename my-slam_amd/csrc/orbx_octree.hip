@@ -166,8 +166,8 @@ __device__ __forceinline__ uint32_t oct_quadrant(const OrbxNode &nd, uint32_t xy
     return (xr < midx ? 0u : 1u) | (yr < midy ? 0u : 2u);      // :517-527
 }
 
-template <int T, int KR>
-__device__ __forceinline__ void oct_body(const OrbxPlan &plan, const OrbxWork &wk, OctShared<T> &sh, const OrbxLevel &L,
+template <int T, int KR, int KS>   // KS: keys per thread that the caller loaded before the candidate count was known (xy0)
+__device__ __forceinline__ void oct_body(const uint32_t *xy0, const OrbxPlan &plan, const OrbxWork &wk, OctShared<T> &sh, const OrbxLevel &L,
                                          const int f, const int l, const int n, const int cap, const int N,
                                          uint32_t *cnt0, uint32_t *cnt1, uint32_t *listA, uint32_t *listB, uint32_t *slotNode,
                                          int *childBase, OrbxNode *lnA, OrbxNode *lnB,
@@ -256,7 +256,7 @@ __device__ __forceinline__ void oct_body(const OrbxPlan &plan, const OrbxWork &w
 #pragma unroll
         for (int u = 0; u < KU; u++) {
             const int k = u * T + tid;
-            xyv[u] = k < n ? cand[k].xy : 0u;
+            xyv[u] = k < n ? (u < KS ? xy0[u < KS ? u : 0] : cand[k].xy) : 0u;
             wv[u] = 0;
         }
     }
@@ -290,12 +290,24 @@ __device__ __forceinline__ void oct_body(const OrbxPlan &plan, const OrbxWork &w
             ai = valid ? offD + (int)g : -1;
         KEYLOOP_END_COUNT(ftCnt)
         __syncthreads();
-        for (int t = D - 1; t >= 0; t--) {                      // key counts of every possible node, leaves up to the roots
+        // key counts of every possible node, leaves up to the roots: levels wider than a wave by the whole workgroup, the
+        // rest (<= 64 nodes each) by wave 0 alone, which needs no workgroup barrier between its levels
+        int t = D - 1;
+        for (; t >= 0 && (nIni << (2 * t)) > 64; t--) {
             const int o = fto(t), o1 = fto(t + 1), cntT = nIni << (2 * t);
             for (int p = tid; p < cntT; p += T) ftCnt[o + p] = ftCnt[o1 + 4 * p] + ftCnt[o1 + 4 * p + 1] + ftCnt[o1 + 4 * p + 2] + ftCnt[o1 + 4 * p + 3];
             __syncthreads();
         }
-        for (int i = tid; i < nIni; i += T) cc[i] = ftCnt[i];
+        if (tid < 64) {
+            for (; t >= 0; t--) {
+                const int o = fto(t), o1 = fto(t + 1), cntT = nIni << (2 * t);
+                if (tid < cntT) ftCnt[o + tid] = ftCnt[o1 + 4 * tid] + ftCnt[o1 + 4 * tid + 1] + ftCnt[o1 + 4 * tid + 2] + ftCnt[o1 + 4 * tid + 3];
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            }
+            for (int i = tid; i < nIni; i += 64) cc[i] = ftCnt[i];
+        }
     } else {
         KEYLOOP_BEGIN(false, true)
             const int xr = (int)(xyv[u] & 0xFFFFu) - ORBX_MINB;
@@ -386,27 +398,35 @@ __device__ __forceinline__ void oct_body(const OrbxPlan &plan, const OrbxWork &w
             if (tid == 0) { atomicOr(&wk.errflags[f], (uint32_t)ERRF_TREE_OVERFLOW); wk.nk[f * plan.nlevels + l] = 0; }
             return;
         }
-        // create the children (:489-537) in creation order; cc becomes the child-id table
+        // create the children (:489-537) in creation order; cc becomes the child-id table.  One thread per (slot, quadrant):
+        // the four lanes of a slot read its four counts (one 16-byte read each), a wave barrier, then each writes its own entry.
         int myExp = 0;
-        for (int s = tid; s < nE; s += T) {
-            const OrbxNode p = lnA[slotNode[s]];
-            int r = 0;
-            for (int q = 0; q < 4; q++) {
-                const int c = (int)cc[4 * s + q];
+        for (int j0 = 0; j0 < 4 * nE; j0 += T) {
+            const int j = j0 + tid;
+            const bool on = j < 4 * nE;
+            const int s = on ? j >> 2 : 0, q = j & 3;
+            const uint4 c4 = *reinterpret_cast<const uint4 *>(&cc[4 * s]);
+            const int c = (int)(q == 0 ? c4.x : q == 1 ? c4.y : q == 2 ? c4.z : c4.w);
+            const int r = (q > 0 && c4.x > 0) + (q > 1 && c4.y > 0) + (q > 2 && c4.z > 0);   // non-empty quadrants before this one
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            if (on) {
                 if (c > 0) {
+                    const uint32_t pi = slotNode[s];
+                    const OrbxNode p = lnA[pi];
                     const int cidx = childBase[s] + r;
                     OrbxNode ch;
                     oct_child_box(p, q, ch);
                     ch.count = c;
                     ch.slot = cidx;
                     lnB[cidx] = ch;
-                    const uint32_t cp = (pathA[slotNode[s]] << 2) | (uint32_t)q;
+                    const uint32_t cp = (pathA[pi] << 2) | (uint32_t)q;
                     pathB[cidx] = cp;
                     if (fast && depth + 1 <= D) ftId[fto(depth + 1) + (int)cp] = (uint32_t)(arenaN + cidx);
                     cc[4 * s + q] = (uint32_t)(arenaN + cidx);
                     nxt[C - 1 - cidx] = (uint32_t)(arenaN + cidx);   // push_front => reversed
                     myExp += c > 1;
-                    r++;
                 } else {
                     cc[4 * s + q] = 0xFFFFFFFFu;
                 }
@@ -601,6 +621,15 @@ __global__ __launch_bounds__(T) void k_octree(OrbxPlan plan, OrbxWork wk)
     uint32_t *owner = wk.owner + (long long)f * plan.cand_frame + L.cand_off;
     int32_t *posOf = reinterpret_cast<int32_t *>(wk.arena + (long long)f * plan.arena_frame + L.arena_off);   // [arena_cap]
     OrbxCand *sel = wk.sel + (long long)f * plan.list_frame + L.list_off;
+    // The first keys of every thread are requested before the candidate count has arrived (one memory round trip instead of
+    // two at the head of the kernel's critical path); what lies past the count is stale data of an earlier call, never used.
+    constexpr int KS = T == 512 ? 12 : 8;
+    uint32_t xy0[KS];
+#pragma unroll
+    for (int u = 0; u < KS; u++) {
+        const int k = u * T + tid;
+        xy0[u] = k < L.cand_cap ? cand[k].xy : 0u;
+    }
     const int n = (int)min(ORBX_CNT(wk, plan, f, l), (uint32_t)L.cand_cap);
     __syncthreads();
     if (tid == 0) {   // self-cleaning: the counter is zero again for the next call (no memset on the hot path)
@@ -611,20 +640,20 @@ __global__ __launch_bounds__(T) void k_octree(OrbxPlan plan, OrbxWork wk)
         if (tid == 0) wk.nk[f * plan.nlevels + l] = 0;
         return;
     }
-#define OCT_ARGS plan, wk, sh, L, f, l, n, cap, N, cnt0, cnt1, listA, listB, slotNode, childBase, lnA, lnB, cand, owner, posOf, sel, pathA, pathB, ftCnt, ftId, D
+#define OCT_ARGS xy0, plan, wk, sh, L, f, l, n, cap, N, cnt0, cnt1, listA, listB, slotNode, childBase, lnA, lnB, cand, owner, posOf, sel, pathA, pathB, ftCnt, ftId, D
     // T = 512 serves the small shapes, many workgroups per CU: stay under 128 VGPRs.  T = 1024 owns its CU anyway.
     if constexpr (T == 512) {
         if (n <= 12 * T)
-            oct_body<T, 12>(OCT_ARGS);
+            oct_body<T, 12, KS>(OCT_ARGS);
         else
-            oct_body<T, 0>(OCT_ARGS);
+            oct_body<T, 0, KS>(OCT_ARGS);
     } else {
         if (n <= 8 * T)
-            oct_body<T, 8>(OCT_ARGS);
+            oct_body<T, 8, KS>(OCT_ARGS);
         else if (n <= 32 * T)
-            oct_body<T, 32>(OCT_ARGS);
+            oct_body<T, 32, KS>(OCT_ARGS);
         else
-            oct_body<T, 0>(OCT_ARGS);
+            oct_body<T, 0, KS>(OCT_ARGS);
     }
 #undef OCT_ARGS
 }
