@@ -259,6 +259,8 @@ def host_api_pass(pkg, frames_np, W, H, NF, device, reps=12):
     import numpy as np
     B = len(frames_np)
     ex = pkg.ORBextractor(NF, 1.2, 8, 20, 7, device=device, max_width=W, max_height=H, max_batch=B)
+    if os.environ.get("ORBX_BENCH_CHUNK"):   # A/B switch: frames per pipeline chunk (library default 16)
+        ex.set_batch_chunk(int(os.environ["ORBX_BENCH_CHUNK"]))
     for _ in range(3):
         ex.extract_batch_raw(frames_np)
     ts = []

@@ -830,14 +830,15 @@ extern "C" int orbx_extract_batch(orbx_extractor *h, const uint8_t *images, int 
     }
     cut.push_back(nframes);
     const int nch = (int)cut.size() - 1;
-    hipStream_t st[2] = {h->stream, h->aux[0]};
+    hipStream_t st[3] = {h->stream, h->aux[0], h->aux[2]};
+    static const int nst = [] { const char *e = getenv("ORBX_BATCH_STREAMS"); const int v = e ? atoi(e) : 3; return v < 1 ? 1 : v > 3 ? 3 : v; }();   // compute streams the chunks rotate over
     const bool have_graphs = !h->bg_off && h->bg_w == width && h->bg_h == height && h->bg_n == nframes && h->bg_chunk == chunk && (int)h->bgraph.size() == nch;
     if (!have_graphs && !h->bg_off) {                       // (re)build the per-chunk graphs for this shape
         for (auto &g : h->bgraph) if (g) (void)hipGraphExecDestroy(g);
         h->bgraph.assign(nch, nullptr);
         bool ok = true;
         for (int c = 0; c < nch && ok; c++) {
-            hipStream_t s = st[c & 1];
+            hipStream_t s = st[c % nst];
             ok = hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal) == hipSuccess;
             if (!ok) break;
             const int rc = enqueue_chunk(h, cut[c], cut[c + 1], width, height, s);
@@ -868,7 +869,7 @@ extern "C" int orbx_extract_batch(orbx_extractor *h, const uint8_t *images, int 
     const double t_begin = trace ? now() : 0;
     for (int c = 0; c < nch; c++) {
         const int k0 = cut[c], k1 = cut[c + 1];
-        hipStream_t s = st[c & 1];
+        hipStream_t s = st[c % nst];
         const double ta = trace ? now() : 0;
         stage_frames(h, images, k0, k1, width, height, row_stride, frame_stride);
         const double tb = trace ? now() : 0;
