@@ -30,7 +30,13 @@ for _ in range(3):
 ts = []
 for _ in range(20):
     t0 = time.perf_counter(); r = ex.extract_batch(frames); ts.append(time.perf_counter() - t0)
-out["host_api_batch64_640x480"] = {"median_ms": round(float(np.median(ts)) * 1e3, 3), "frames_per_s": round(64 / float(np.median(ts)), 1)}
+out["host_api_batch64_640x480"] = {"median_ms": round(float(np.median(ts)) * 1e3, 3), "frames_per_s": round(64 / float(np.median(ts)), 1),
+                                   "note": "Python wrapper extract_batch: the C call plus 64 per-frame array slices built in Python"}
+ts = []
+for _ in range(20):
+    t0 = time.perf_counter(); r = ex.extract_batch_raw(frames); ts.append(time.perf_counter() - t0)
+out["host_api_batch64_640x480_c_call"] = {"median_ms": round(float(np.median(ts)) * 1e3, 3), "frames_per_s": round(64 / float(np.median(ts)), 1),
+                                          "note": "orbx_extract_batch itself (flat output arrays), as bench.py's host_api"}
 del ex
 
 # ---- other shapes, device API ----
