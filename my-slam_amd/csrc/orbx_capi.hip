@@ -236,6 +236,8 @@ static int make_plan(const orbx_extractor *h, int W, int H, OrbxPlan *P, std::st
             while (d > 0 && (long long)L.nIni * (((1ll << (2 * (d + 1))) - 1) / 3) > 2800) d--;
             L.fastD = d;
             P->oct_ft = std::max(P->oct_ft, (int)(L.nIni * (((1ll << (2 * (d + 1))) - 1) / 3)));
+            // per-coordinate path tables of the fast-forward (k_octree): one u16 per column and per row of the level's box
+            if (d > 0) P->oct_map = std::max(P->oct_map, (int)align_up((size_t)std::max(L.maxBX - ORBX_MINB, 1), 8) + (int)align_up((size_t)std::max(L.maxBY - ORBX_MINB, 1), 8));
         }
         L.cand_off = cand_off; cand_off += (L.cand_cap + 15) / 16 * 16;
         L.list_cap = L.nCols > 0 ? (std::max(L.quota + 3, 4 * L.nIni) + 1 + 3) / 4 * 4 : 0;
@@ -333,7 +335,7 @@ extern "C" int orbx_create(orbx_extractor **out, int nfeatures, float scale_fact
     int max_list = 0;
     for (int l = 0; l < nlevels; l++) max_list = std::max(max_list, h->max_plan.lv[l].list_cap);
     h->oct_cap_max = std::max(max_list, 8);
-    h->oct_lds = orbx_octree_lds_bytes(h->oct_cap_max, 0);
+    h->oct_lds = orbx_octree_lds_bytes(h->oct_cap_max, 0, 0);
     if (h->oct_lds > 150 * 1024) { delete h; return fail(ORBX_E_INVALID, "nfeatures=%d needs %zu B of LDS for the quadtree (max 153600)", nfeatures, h->oct_lds); }
 
 #define ALLOC(ptr, bytes)                                                                       \
@@ -660,10 +662,10 @@ static int enqueue(orbx_extractor *h, const uint8_t *d_images, int nframes, int 
     }
     if (pe) HIPCHK(hipEventRecord(pe[2], s));
     {   // dynamic LDS of the launch: the list arrays for the handle's largest list + this shape's fast-forward tables
-        size_t lds = orbx_octree_lds_bytes(h->oct_cap_max, P.oct_ft);
+        size_t lds = orbx_octree_lds_bytes(h->oct_cap_max, P.oct_ft, P.oct_map);
         if (lds > 150 * 1024) {              // no room for the tables beside very long lists: plain passes
-            for (int i = 0; i < nsub; i++) { sp[i].oct_ft = 0; for (int l = 0; l < h->nlevels; l++) sp[i].lv[l].fastD = 0; }
-            lds = orbx_octree_lds_bytes(h->oct_cap_max, 0);
+            for (int i = 0; i < nsub; i++) { sp[i].oct_ft = 0; sp[i].oct_map = 0; for (int l = 0; l < h->nlevels; l++) sp[i].lv[l].fastD = 0; }
+            lds = orbx_octree_lds_bytes(h->oct_cap_max, 0, 0);
         }
         for (int i = 0; i < nsub; i++) { sp[i].oct_cap_max = h->oct_cap_max; orbx_launch_octree(sp[i], sw[i], f0[i + 1] - f0[i], lds, st[i]); }
     }

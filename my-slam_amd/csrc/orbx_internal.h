@@ -106,6 +106,7 @@ struct OrbxPlan {
     int ncells;                   // cells per frame over all levels
     int blur_mode;
     int oct_ft;                   // quadtree fast-forward table entries (max over levels of nIni * (4^(fastD+1) - 1) / 3)
+    int oct_map;                  // quadtree coordinate -> path-bits tables: u16 entries (max over levels of box width + box height, padded)
     int oct_cap_max;              // largest list capacity the launch's LDS is sized for (the handle's maximum shape)
     int oct_big;                  // some level is 1080p-class (tens of thousands of candidates): quadtree workgroups of 1024 threads
     int out_cap;                  // per-frame output capacity
@@ -152,6 +153,6 @@ void orbx_launch_octree(const OrbxPlan &plan, const OrbxWork &wk, int nframes, s
 void orbx_launch_describe(const OrbxPlan &plan, const OrbxWork &wk, int nframes,
                           orbx_keypoint *d_kps, uint8_t *d_desc, int32_t *d_counts,
                           int32_t *d_status, hipStream_t s);
-size_t orbx_octree_lds_bytes(int list_cap_max, int ft_entries);
+size_t orbx_octree_lds_bytes(int list_cap_max, int ft_entries, int map_entries);
 int orbx_upload_constants(const int umax[16], const int gauss_k[7]);
 int orbx_selftest_fp16(void);   // 0 = fp16 subnormal arithmetic behaves as k_fast_cells needs

@@ -173,7 +173,7 @@ __device__ __forceinline__ void oct_body(const uint32_t *xy0, const OrbxPlan &pl
                                          int *childBase, OrbxNode *lnA, OrbxNode *lnB,
                                          const OrbxCand *__restrict__ cand, uint32_t *__restrict__ owner,
                                          int32_t *__restrict__ posOf, OrbxCand *__restrict__ sel,
-                                         uint32_t *pathA, uint32_t *pathB, uint32_t *ftCnt, uint32_t *ftId, const int D)
+                                         uint32_t *pathA, uint32_t *pathB, uint32_t *ftCnt, uint32_t *ftId, uint16_t *mapXY, const int D)
 {
     // Fast-forward of the early passes (D > 0).  While every splittable node is split, what a pass does to the KEYS is known
     // in advance: a key ends up in the depth-t node whose box contains it, and the boxes are a function of the root box alone
@@ -271,20 +271,42 @@ __device__ __forceinline__ void oct_body(const uint32_t *xy0, const OrbxPlan &pl
     }
     __syncthreads();
     if (D > 0) {
+        // A key's path = D quadrant choices.  The x choices depend on x alone (the root and, level after level, which half of the
+        // current x range the key is in) and the y choices on y alone, so the box's columns and rows get their D choices ONCE, spread
+        // to the even / odd bit positions of the path, and a key's path is two table reads and an OR instead of D rounds of
+        // DivideNode arithmetic (:485-528) -- that loop was 20 of the 27 us this section took for the 24 k keys of a 1080p level 0.
         const int offD = fto(D);
-        KEYLOOP_BEGIN(false, true)
-            const int xr = (int)(xyv[u] & 0xFFFFu) - ORBX_MINB, yr = (int)(xyv[u] >> 16) - ORBX_MINB;
+        const int boxW = L.maxBX - ORBX_MINB;
+        uint16_t *mapX = mapXY, *mapY = mapXY + ((boxW + 7) & ~7);
+        for (int xr = tid; xr < boxW; xr += T) {
             int b = (int)__fdiv_rn((float)xr, L.hX);
             b = min(max(b, 0), nIni - 1);
-            int x0 = (int)__fmul_rn(L.hX, (float)b), x1 = (int)__fmul_rn(L.hX, (float)(b + 1)), y0 = 0, y1 = boxH;
+            int x0 = (int)__fmul_rn(L.hX, (float)b), x1 = (int)__fmul_rn(L.hX, (float)(b + 1));
             uint32_t g = (uint32_t)b;
-            for (int t = 0; t < D; t++) {                       // DivideNode's boxes along the key's path (:485-528)
-                const int midx = x0 + ((x1 - x0 + 1) >> 1), midy = y0 + ((y1 - y0 + 1) >> 1);
-                const uint32_t qx = xr < midx ? 0u : 1u, qy = yr < midy ? 0u : 1u;
+            for (int t = 0; t < D; t++) {
+                const int midx = x0 + ((x1 - x0 + 1) >> 1);
+                const uint32_t qx = xr < midx ? 0u : 1u;
                 x0 = qx ? midx : x0; x1 = qx ? x1 : midx;
-                y0 = qy ? midy : y0; y1 = qy ? y1 : midy;
-                g = (g << 2) | qx | (qy << 1);
+                g = (g << 2) | qx;
             }
+            mapX[xr] = (uint16_t)g;           // root << 2D | x choices at the even bits (nIni << 2D <= 2800: checked at plan time)
+        }
+        for (int yr = tid; yr < boxH; yr += T) {
+            int y0 = 0, y1 = boxH;
+            uint32_t g = 0;
+            for (int t = 0; t < D; t++) {
+                const int midy = y0 + ((y1 - y0 + 1) >> 1);
+                const uint32_t qy = yr < midy ? 0u : 1u;
+                y0 = qy ? midy : y0; y1 = qy ? y1 : midy;
+                g = (g << 2) | (qy << 1);
+            }
+            mapY[yr] = (uint16_t)g;           // y choices at the odd bits
+        }
+        __syncthreads();
+        KEYLOOP_BEGIN(false, true)
+            const uint32_t xr = min((xyv[u] & 0xFFFFu) - (uint32_t)ORBX_MINB, (uint32_t)(boxW - 1));   // keys lie inside the box; the clamps only
+            const uint32_t yr = min((xyv[u] >> 16) - (uint32_t)ORBX_MINB, (uint32_t)(boxH - 1));       // keep a stray coordinate inside the tables
+            const uint32_t g = (uint32_t)mapX[xr] | (uint32_t)mapY[yr];
             if (!REG && valid) owner[k] = g;
             wv[u] = g;
             ai = valid ? offD + (int)g : -1;
@@ -343,6 +365,7 @@ __device__ __forceinline__ void oct_body(const uint32_t *xy0, const OrbxPlan &pl
     int m = sh.m, arenaN = nIni, lastBase = 0, lastC = nIni, phaseB = 0;
     int depth = 0;                 // depth of the nodes in the window lnA
     bool fast = D > 0;             // the keys still carry their paths (wv = leaf g), not node ids
+    int leaf_tmax = -1;            // >= 0: the tree finished while the keys still carried their paths (see the selection)
     // first DivideNode of every splittable root: slots, then the quadrant counts (from the table, or one key loop)
     int nAlive = oct_assign_slots<T>(lnA, lastC, true, false, slotNode, reinterpret_cast<unsigned long long *>(cn), sh, scanp);
     __syncthreads();
@@ -461,10 +484,10 @@ __device__ __forceinline__ void oct_body(const uint32_t *xy0, const OrbxPlan &pl
         __syncthreads();
         if (done && fast) {
             // the keys still carry their paths: the node of a key is the deepest created node on its path
+            // -- resolved once per LEAF (a few thousand) instead of once per key, and straight to the node's position in the final
+            // list: the selection below reads it from leafPos[path] (the leaf counts' row of the table, dead by now)
             __syncthreads();       // ftId of this pass's children
-            KEYLOOP_BEGIN(true, false)
-                SETOWN(ft_lookup(wv[u], min(depth + 1, D)));
-            KEYLOOP_END
+            leaf_tmax = min(depth + 1, D);
             m = newM;
             { uint32_t *t2 = cur; cur = nxt; nxt = t2; }
             break;
@@ -543,6 +566,12 @@ __device__ __forceinline__ void oct_body(const uint32_t *xy0, const OrbxPlan &pl
     }
     __threadfence_block();
     __syncthreads();
+    uint32_t *leafPos = ftCnt + fto(D);
+    if (leaf_tmax >= 0) {
+        const int nleaf = nIniF << (2 * D);
+        for (int g = tid; g < nleaf; g += T) leafPos[g] = (uint32_t)posOf[ft_lookup((uint32_t)g, leaf_tmax)];
+        __syncthreads();
+    }
     for (int kb = 0; kb < n; kb += T * KU) {
 #pragma unroll
         for (int u0 = 0; u0 < KU; u0 += 8) {      // 8 keys at a time: issue the loads, then the updates
@@ -554,7 +583,7 @@ __device__ __forceinline__ void oct_body(const uint32_t *xy0, const OrbxPlan &pl
                 const int k = kb + (u0 + j) * T + tid;
                 if (u0 + j < KU && k < n) {
                     const uint32_t own = REG ? wv[(u0 + j) % KU] : owner[k];
-                    posv[j] = posOf[own & OCT_ID_MASK];
+                    posv[j] = leaf_tmax >= 0 ? (int)leafPos[own] : posOf[own & OCT_ID_MASK];   // fast finish: own is still the key's path
                     rv[j] = cand[k].resp;
                     xv[j] = REG ? xyv[(u0 + j) % KU] : cand[k].xy;
                 }
@@ -615,6 +644,7 @@ __global__ __launch_bounds__(T) void k_octree(OrbxPlan plan, OrbxWork wk)
     // arrays of the LARGEST list of the launch (the dynamic LDS size is one number per launch).
     uint32_t *ftCnt = reinterpret_cast<uint32_t *>(oct_lds + (size_t)plan.oct_cap_max * 88);
     uint32_t *ftId = ftCnt + plan.oct_ft;
+    uint16_t *mapXY = reinterpret_cast<uint16_t *>(ftId + plan.oct_ft);    // [oct_map] path bits per box column, then per box row (oct_body)
     const int D = L.fastD;
 
     const OrbxCand *cand = wk.cand + (long long)f * plan.cand_frame + L.cand_off;
@@ -640,7 +670,7 @@ __global__ __launch_bounds__(T) void k_octree(OrbxPlan plan, OrbxWork wk)
         if (tid == 0) wk.nk[f * plan.nlevels + l] = 0;
         return;
     }
-#define OCT_ARGS xy0, plan, wk, sh, L, f, l, n, cap, N, cnt0, cnt1, listA, listB, slotNode, childBase, lnA, lnB, cand, owner, posOf, sel, pathA, pathB, ftCnt, ftId, D
+#define OCT_ARGS xy0, plan, wk, sh, L, f, l, n, cap, N, cnt0, cnt1, listA, listB, slotNode, childBase, lnA, lnB, cand, owner, posOf, sel, pathA, pathB, ftCnt, ftId, mapXY, D
     // T = 512 serves the small shapes, many workgroups per CU: stay under 128 VGPRs.  T = 1024 owns its CU anyway.
     if constexpr (T == 512) {
         if (n <= 12 * T)
@@ -658,7 +688,7 @@ __global__ __launch_bounds__(T) void k_octree(OrbxPlan plan, OrbxWork wk)
 #undef OCT_ARGS
 }
 
-size_t orbx_octree_lds_bytes(int list_cap_max, int ft_entries) { return (size_t)list_cap_max * 88 + (size_t)ft_entries * 8; }
+size_t orbx_octree_lds_bytes(int list_cap_max, int ft_entries, int map_entries) { return (size_t)list_cap_max * 88 + (size_t)ft_entries * 8 + (size_t)map_entries * 2; }
 
 void orbx_launch_octree(const OrbxPlan &plan, const OrbxWork &wk, int nframes, size_t lds_bytes, hipStream_t s)
 {
