@@ -97,6 +97,29 @@ def test_batch_chunked_pipeline_equals_plain(orbx, synth):
     _compare(plain[0][B - 1, :n], plain[1][B - 1, :n], okps, odesc, "last frame")
 
 
+def test_batch_page_locked_input_equals_pageable(orbx, synth):
+    """orbx_extract_batch uploads page-locked caller memory where it lies (no staging copy): same result as from pageable memory, for a
+    contiguous batch (one tall 2-D copy per chunk) and for a padded row pitch (re-pitched by the copy)."""
+    import torch
+    W, H, B = 322, 241, 18
+    for padw in (0, 14):
+        pad = np.zeros((B, H, W + padw), np.uint8)
+        pad[:, :, :W] = synth.stream(11, W, H, B)
+        frames = pad[:, :, :W]
+        ex = orbx.ORBextractor(500, max_width=W, max_height=H, max_batch=B)
+        ex.set_batch_chunk(4)
+        ref = tuple(a.copy() for a in ex.extract_batch_raw(frames))
+        pinned_full = torch.from_numpy(pad).pin_memory().numpy()
+        pinned = pinned_full[:, :, :W]
+        assert pinned.strides == frames.strides
+        for rep in range(3):
+            k, d, c = ex.extract_batch_raw(pinned)
+            assert np.array_equal(c, ref[2]), (padw, rep)
+            for f in range(B):
+                n = int(c[f])
+                assert k[f, :n].tobytes() == ref[0][f, :n].tobytes() and np.array_equal(d[f, :n], ref[1][f, :n]), (padw, rep, f)
+
+
 # ---- committed fixtures: no oracle build needed for these ----
 import glob
 import os
