@@ -137,6 +137,7 @@ struct orbx_extractor {
     uint8_t *h_in = nullptr;
     orbx_keypoint *h_kps = nullptr; uint8_t *h_desc = nullptr; int32_t *h_counts = nullptr, *h_status = nullptr;
     uint8_t *d_out = nullptr, *h_out = nullptr; size_t out_hdr = 0, out_kps_bytes = 0, out_bytes = 0;   // the block the eight pointers above point into
+    std::vector<size_t> chunk_off;   // orbx_extract_batch: byte offset of every chunk's own [counts | status | keypoints | descriptors] block in d_out / h_out
     int inflight = 0, inflight_frames = 0;      // orbx_extract_begin / orbx_extract_end
     // orbx_extract_begin replays one HIP graph per shape (upload, ~10 kernels, download) instead of ~12 launches
     hipGraphExec_t graph_exec = nullptr; int graph_w = 0, graph_h = 0, graph_seen_w = 0, graph_seen_h = 0; bool graph_off = false;
@@ -377,6 +378,7 @@ extern "C" int orbx_create(orbx_extractor **out, int nfeatures, float scale_fact
     h->out_hdr = align_up(2 * B * sizeof(int32_t), 256);
     h->out_kps_bytes = B * M.out_cap * sizeof(orbx_keypoint);
     h->out_bytes = h->out_hdr + h->out_kps_bytes + B * M.out_cap * 32;
+    h->out_bytes += 256 * (B + 2);   // per-chunk blocks of orbx_extract_batch: one aligned header per chunk instead of one per batch
     ALLOC(h->d_out, h->out_bytes);
 #undef ALLOC
     if (hipHostMalloc((void **)&h->h_in, B * h->in_frame + 256) != hipSuccess ||
@@ -758,20 +760,23 @@ static void stage_frames(orbx_extractor *h, const uint8_t *images, int k0, int k
     else for (int u = 0; u < n; u++) unit(u);
 }
 
-static int deliver_batch(orbx_extractor *h, int k0, int k1, orbx_keypoint *keypoints, uint8_t *descriptors, int cap, int *counts)
+// hand frames [k0, k1) over to the caller; hc / hs / hk / hd = counts, status, keypoints, descriptors of frame k0 in pinned memory
+static int deliver_batch(orbx_extractor *h, int k0, int k1, orbx_keypoint *keypoints, uint8_t *descriptors, int cap, int *counts,
+                         const int32_t *hc, const int32_t *hs, const orbx_keypoint *hk, const uint8_t *hd)
 {
     const int ocap = h->max_plan.out_cap;
     for (int k = k0; k < k1; k++) {
-        if (h->h_status[k] != ORBX_OK)
-            return fail(h->h_status[k], "frame %d: device status %d (%s)", k, h->h_status[k],
-                        h->h_status[k] == ORBX_E_CAND_OVERFLOW ? "FAST candidate buffer overflow" :
-                        h->h_status[k] == ORBX_E_TREE_OVERFLOW ? "quadtree arena overflow" : "capacity");
-        if (h->h_counts[k] > cap) return fail(ORBX_E_CAPACITY, "frame %d produced %d keypoints, caller capacity %d (use orbx_capacity())", k, h->h_counts[k], cap);
+        const int st = hs[k - k0];
+        if (st != ORBX_OK)
+            return fail(st, "frame %d: device status %d (%s)", k, st,
+                        st == ORBX_E_CAND_OVERFLOW ? "FAST candidate buffer overflow" :
+                        st == ORBX_E_TREE_OVERFLOW ? "quadtree arena overflow" : "capacity");
+        if (hc[k - k0] > cap) return fail(ORBX_E_CAPACITY, "frame %d produced %d keypoints, caller capacity %d (use orbx_capacity())", k, hc[k - k0], cap);
     }
     auto unit = [&](int u) {
-        const int k = k0 + u, n = h->h_counts[k];
-        memcpy(keypoints + (size_t)k * cap, h->h_kps + (size_t)k * ocap, sizeof(orbx_keypoint) * n);
-        memcpy(descriptors + (size_t)k * cap * 32, h->h_desc + (size_t)k * ocap * 32, (size_t)32 * n);
+        const int k = k0 + u, n = hc[u];
+        memcpy(keypoints + (size_t)k * cap, hk + (size_t)u * ocap, sizeof(orbx_keypoint) * n);
+        memcpy(descriptors + (size_t)k * cap * 32, hd + (size_t)u * ocap * 32, (size_t)32 * n);
         counts[k] = n;
     };
     if (h->pool && k1 - k0 >= 8) h->pool->parallel_for(k1 - k0, unit);
@@ -802,20 +807,35 @@ static int extract_batch_simple(orbx_extractor *h, const uint8_t *images, int nf
     HIPCHK(hipStreamSynchronize(s));
     rc = finish_profile(h);
     if (rc != ORBX_OK) return rc;
-    return deliver_batch(h, 0, nframes, keypoints, descriptors, cap, counts);
+    return deliver_batch(h, 0, nframes, keypoints, descriptors, cap, counts, h->h_counts, h->h_status, h->h_kps, h->h_desc);
 }
 
-// kernels + download of frames [k0, k1) of the handle's own input block, on stream s
-static int enqueue_chunk(orbx_extractor *h, int k0, int k1, int width, int height, hipStream_t s)
+// Chunk c's outputs live in a block of their own, [counts nf | status nf | (pad to 256) | keypoints nf x cap | descriptors nf x cap x 32]
+// at chunk_off[c] of d_out / h_out, so that they come back with ONE copy (a device-to-host copy on a compute stream is ~8 us of
+// stream time whatever its size; a chunk had four).
+struct ChunkBlock { int32_t *counts, *status; orbx_keypoint *kps; uint8_t *desc; size_t bytes; };
+static ChunkBlock chunk_block(const orbx_extractor *h, uint8_t *base, int c, int nf)
 {
-    const int ocap = h->max_plan.out_cap, nf = k1 - k0;
+    const int ocap = h->max_plan.out_cap;
+    uint8_t *b = base + h->chunk_off[c];
+    const size_t hdr = align_up((size_t)2 * nf * sizeof(int32_t), 256);
+    ChunkBlock B;
+    B.counts = reinterpret_cast<int32_t *>(b); B.status = B.counts + nf;
+    B.kps = reinterpret_cast<orbx_keypoint *>(b + hdr);
+    B.desc = b + hdr + (size_t)nf * ocap * sizeof(orbx_keypoint);
+    B.bytes = hdr + (size_t)nf * ocap * (sizeof(orbx_keypoint) + 32);
+    return B;
+}
+
+// kernels + download of frames [k0, k1) = chunk c of the handle's own input block, on stream s
+static int enqueue_chunk(orbx_extractor *h, int c, int k0, int k1, int width, int height, hipStream_t s)
+{
+    const int nf = k1 - k0;
+    const ChunkBlock D = chunk_block(h, h->d_out, c, nf);
     int rc = enqueue(h, h->d_input + (size_t)k0 * h->in_frame, nf, width, height, h->in_stride, (long long)h->in_frame,
-                     h->d_kps + (size_t)k0 * ocap, h->d_desc + (size_t)k0 * ocap * 32, h->d_counts + k0, h->d_status + k0, s, k0);
+                     D.kps, D.desc, D.counts, D.status, s, k0);
     if (rc != ORBX_OK) return rc;
-    HIPCHK(hipMemcpyAsync(h->h_counts + k0, h->d_counts + k0, sizeof(int32_t) * nf, hipMemcpyDeviceToHost, s));
-    HIPCHK(hipMemcpyAsync(h->h_status + k0, h->d_status + k0, sizeof(int32_t) * nf, hipMemcpyDeviceToHost, s));
-    HIPCHK(hipMemcpyAsync(h->h_kps + (size_t)k0 * ocap, h->d_kps + (size_t)k0 * ocap, sizeof(orbx_keypoint) * (size_t)ocap * nf, hipMemcpyDeviceToHost, s));
-    HIPCHK(hipMemcpyAsync(h->h_desc + (size_t)k0 * ocap * 32, h->d_desc + (size_t)k0 * ocap * 32, (size_t)32 * ocap * nf, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipMemcpyAsync(h->h_out + h->chunk_off[c], h->d_out + h->chunk_off[c], D.bytes, hipMemcpyDeviceToHost, s));
     return ORBX_OK;
 }
 
@@ -859,6 +879,16 @@ extern "C" int orbx_extract_batch(orbx_extractor *h, const uint8_t *images, int 
     }
     cut.push_back(nframes);
     const int nch = (int)cut.size() - 1;
+    {   // every chunk's output block (the graphs below are captured with these addresses; they depend on (nframes, chunk) only)
+        h->chunk_off.assign(nch, 0);
+        size_t off = 0;
+        for (int c = 0; c < nch; c++) {
+            const int nf = cut[c + 1] - cut[c];
+            h->chunk_off[c] = off;
+            off += align_up((size_t)2 * nf * sizeof(int32_t), 256) + (size_t)nf * h->max_plan.out_cap * (sizeof(orbx_keypoint) + 32);
+        }
+        if (off > h->out_bytes) return fail(ORBX_E_INVALID, "internal: chunk output blocks exceed the staging block");
+    }
     hipStream_t st[3] = {h->stream, h->aux[0], h->aux[2]};
     static const int nst = [] { const char *e = getenv("ORBX_BATCH_STREAMS"); const int v = e ? atoi(e) : 3; return v < 1 ? 1 : v > 3 ? 3 : v; }();   // compute streams the chunks rotate over
     const bool have_graphs = !h->bg_off && h->bg_w == width && h->bg_h == height && h->bg_n == nframes && h->bg_chunk == chunk && (int)h->bgraph.size() == nch;
@@ -870,7 +900,7 @@ extern "C" int orbx_extract_batch(orbx_extractor *h, const uint8_t *images, int 
             hipStream_t s = st[c % nst];
             ok = hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal) == hipSuccess;
             if (!ok) break;
-            const int rc = enqueue_chunk(h, cut[c], cut[c + 1], width, height, s);
+            const int rc = enqueue_chunk(h, c, cut[c], cut[c + 1], width, height, s);
             hipGraph_t g = nullptr;
             const hipError_t e = hipStreamEndCapture(s, &g);
             ok = rc == ORBX_OK && e == hipSuccess && g && hipGraphInstantiate(&h->bgraph[c], g, nullptr, nullptr, 0) == hipSuccess;
@@ -912,7 +942,7 @@ extern "C" int orbx_extract_batch(orbx_extractor *h, const uint8_t *images, int 
         HIPCHK(hipEventRecord(h->ev_up[c], up));
         HIPCHK(hipStreamWaitEvent(s, h->ev_up[c], 0));
         if (graphs) HIPCHK(hipGraphLaunch(h->bgraph[c], s));
-        else { int rc = enqueue_chunk(h, k0, k1, width, height, s); if (rc != ORBX_OK) return rc; }
+        else { int rc = enqueue_chunk(h, c, k0, k1, width, height, s); if (rc != ORBX_OK) return rc; }
         HIPCHK(hipEventRecord(h->ev_done[c], s));
         if (trace) { t_stage += tb - ta; t_launch += now() - tb; }
     }
@@ -925,7 +955,10 @@ extern "C" int orbx_extract_batch(orbx_extractor *h, const uint8_t *images, int 
         const double tw = trace ? now() : 0;
         HIPCHK(hipEventSynchronize(h->ev_done[c]));
         if (trace) t_wait += now() - tw;
-        if (rcd == ORBX_OK) rcd = deliver_batch(h, k0, k1, keypoints, descriptors, cap, counts);
+        if (rcd == ORBX_OK) {
+            const ChunkBlock Hb = chunk_block(h, h->h_out, c, k1 - k0);
+            rcd = deliver_batch(h, k0, k1, keypoints, descriptors, cap, counts, Hb.counts, Hb.status, Hb.kps, Hb.desc);
+        }
     }
     HIPCHK(hipStreamSynchronize(up));
     h->last_input = h->d_input; h->last_in_stride = h->in_stride; h->last_in_frame = (long long)h->in_frame; h->last_batch = nframes;
