@@ -362,6 +362,7 @@ extern "C" int orbx_create(orbx_extractor **out, int nfeatures, float scale_fact
     h->bands_cap = 2 * ((size_t)max_height / 8 + 4) * ORBX_MAX_LEVELS;
     ALLOC(h->d_bands, h->bands_cap * sizeof(int4));
     { const char *e = getenv("ORBX_PYRAMID_FUSE"); if (e) h->fuse_on = atoi(e); }
+    { const char *e = getenv("ORBX_OVERLAP_PYRAMID"); if (e) h->overlap_pyr = atoi(e) != 0; }   // A/B switch for ORBX_OPT_OVERLAP_PYRAMID
     h->cells_cap = h->max_plan.ncells + 64 * nlevels;   // a smaller frame never has more cells; slack for rounding
     ALLOC(h->d_cells, (size_t)h->cells_cap * sizeof(uint32_t));
     const OrbxPlan &M = h->max_plan;

@@ -24,6 +24,13 @@ ts = []
 for _ in range(300):
     t0 = time.perf_counter(); k, d = ex(img); ts.append(time.perf_counter() - t0)
 out["host_api_single_640x480"] = {"median_ms": round(float(np.median(ts)) * 1e3, 4), "frames_per_s": round(1 / float(np.median(ts)), 1), "keypoints": len(k)}
+ex1 = M.ORBextractor(1000, max_width=640, max_height=480)          # a handle for one frame at a time (the SLAM case): one HIP graph per call
+for _ in range(20):
+    ex1(img)
+ts = []
+for _ in range(300):
+    t0 = time.perf_counter(); k, d = ex1(img); ts.append(time.perf_counter() - t0)
+out["host_api_single_640x480_one_frame_handle"] = {"median_ms": round(float(np.median(ts)) * 1e3, 4), "frames_per_s": round(1 / float(np.median(ts)), 1), "keypoints": len(k)}
 frames = synth.stream(4, 640, 480, 64)
 for _ in range(3):
     ex.extract_batch(frames)
