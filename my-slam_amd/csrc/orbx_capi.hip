@@ -556,7 +556,9 @@ static int ensure_plan(orbx_extractor *h, int W, int H)
         }
     }
     P.cell_tab = h->d_cells;
-    HIPCHK(hipStreamSynchronize(h->stream));
+    // a shape change rewrites tables that kernels of an earlier call may still be reading -- on the handle's stream, its aux
+    // streams or a caller's stream (orbx_extract_batch_device): wait for the device, not only for h->stream (shape changes are rare)
+    HIPCHK(hipDeviceSynchronize());
     if (!bands.empty()) HIPCHK(hipMemcpy(h->d_bands, bands.data(), bands.size() * sizeof(int4), hipMemcpyHostToDevice));
     HIPCHK(hipMemcpy(h->d_cells, cells.data(), (size_t)P.ncells * sizeof(uint32_t), hipMemcpyHostToDevice));
     HIPCHK(hipMemcpy(h->d_tab_i, ti.data(), e * sizeof(int), hipMemcpyHostToDevice));
@@ -701,6 +703,7 @@ extern "C" int orbx_extract_batch_device(orbx_extractor *h, const uint8_t *d_ima
                                          int32_t *d_counts, int32_t *d_status, void *hip_stream)
 {
     if (!h) return fail(ORBX_E_INVALID, "NULL handle");
+    if (h->inflight) return fail(ORBX_E_INVALID, "an orbx_extract_begin call is in flight on this handle (its workspace would be overwritten)");
     if (!d_images || !d_keypoints || !d_descriptors || !d_counts || !d_status) return fail(ORBX_E_INVALID, "NULL device pointer");
     if (nframes < 1 || nframes > h->max_batch) return fail(ORBX_E_INVALID, "nframes=%d (max_batch=%d)", nframes, h->max_batch);
     if (width < 1 || height < 1 || row_stride < width) return fail(ORBX_E_INVALID, "bad frame geometry %dx%d stride %d", width, height, row_stride);

@@ -314,6 +314,13 @@ def test_extract_begin_end_pipelined(orbx, synth):
         ex[0].extract_begin(frames[1])
     with pytest.raises(orbx.OrbxError):
         ex[0](frames[1])
+    import torch                                # the device-buffer entry point would overwrite the pending call's workspace too
+    fr = torch.from_numpy(frames[:1]).cuda()
+    cap = ex[0].cap
+    dk = torch.zeros((1, cap, 7), dtype=torch.float32, device="cuda"); dd = torch.zeros((1, cap, 32), dtype=torch.uint8, device="cuda")
+    dc = torch.zeros(1, dtype=torch.int32, device="cuda"); ds = torch.zeros(1, dtype=torch.int32, device="cuda")
+    with pytest.raises(orbx.OrbxError):
+        ex[0].extract_batch_device(fr.data_ptr(), 1, W, H, fr.stride(1), fr.stride(0), dk.data_ptr(), dd.data_ptr(), dc.data_ptr(), ds.data_ptr())
     kp, de = ex[0].extract_end()
     assert kp.tobytes() == want[0][0].tobytes()
     with pytest.raises(orbx.OrbxError):
