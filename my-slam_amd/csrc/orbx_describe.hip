@@ -57,7 +57,7 @@ int orbx_upload_constants(const int umax[16], const int gauss_k[7])
             for (int j = 0; j < 37; j++) need[i][j] = (double)((i - 18) * (i - 18) + (j - 18) * (j - 18)) <= R * R;
         static uint32_t rt[192], ct[320];
         int nr = 0, nc = 0;
-        for (int rp = 0; rp < 22; rp++)
+        for (int rp = 21; rp >= 0; rp--)           // highest row pair first: see DescLds (the row pass runs in place)
             for (int gq = 0; gq < 10; gq++) {
                 bool ok = false;
                 for (int row = 2 * rp; row <= 2 * rp + 1; row++)
@@ -196,10 +196,17 @@ extern "C" int orbx_debug_sincos(const float *h_theta, float *h_cos, float *h_si
 #define DW_P_ROWS 22
 #define DW_BL_STRIDE 40
 
+// raw, P and bl share ONE buffer (3520 B per wave instead of 5632: 11 workgroups per CU by LDS instead of 7).  raw (2112 B) and bl
+// (1520 B) start at byte 0 like P.  That works because the passes walk it in the right direction and a wave's LDS instructions
+// execute in order (all loads of a pass iteration are issued before its stores):
+//   row pass     reads raw row pair r (bytes 96 r ..) and writes P row pair r (bytes 160 r ..), HIGHEST pair first: what an
+//                iteration writes lies above every raw row the later iterations still read (160 r >= 96 (r' + 1) for r' < r);
+//   column pass  reads P pairs q .. q + 3 and writes bl rows 2q, 2q + 1 (bytes 80 q .. 80 q + 120), LOWEST q first: below every P
+//                pair a later iteration reads (160 q' for q' >= q, q >= 2; the first iteration holds q = 0 .. 3 entirely).
 struct __attribute__((aligned(16))) DescLds {
-    uint8_t raw[DW_RAW_STRIDE * DW_RAW_ROWS];   // 2112 B (bl aliases this)
-    uint32_t P[DW_P_STRIDE * DW_P_ROWS];        // 3520 B
+    uint8_t buf[DW_P_STRIDE * DW_P_ROWS * 4];   // 3520 B
 };
+
 
 // a wave-uniform pointer pinned to scalar registers (keeps "scalar base + 32-bit lane offset" from being re-associated into
 // 64-bit vector arithmetic)
@@ -235,7 +242,8 @@ __device__ __forceinline__ int wave_sum_dpp(int v)
 
 ORBX_TRACE_DEFINE(g_desc_trace, orbx_debug_desc_trace)
 
-__global__ __launch_bounds__(256) void k_describe(
+// 8 waves per SIMD: 63 VGPRs (68 without the bound) and 14 KB of LDS per workgroup; this kernel hides its latencies with resident waves
+__global__ __launch_bounds__(256, 8) void k_describe(
     OrbxPlan plan, OrbxWork wk, orbx_keypoint *__restrict__ kps, uint8_t *__restrict__ desc,
     int32_t *__restrict__ counts, int32_t *__restrict__ status, int l0_aligned, int wg_per_frame, int nwg, uint32_t wg_rcp)
 {
@@ -304,7 +312,7 @@ __global__ __launch_bounds__(256) void k_describe(
         const int rr = lane / 12, d = lane - rr * 12;
         const int step5 = 5 * L.stride;
         if (lane < 60 && d < 11) {
-            uint32_t *dst = reinterpret_cast<uint32_t *>(&S.raw[rr * DW_RAW_STRIDE + 4 * d]);
+            uint32_t *dst = reinterpret_cast<uint32_t *>(&S.buf[rr * DW_RAW_STRIDE + 4 * d]);
             U2a4 gv[9];
             if (l != 0 || l0_aligned) {   // rows start on a dword: one shift for the whole tile
                 // byte offsets inside one frame fit 31 bits; one 24-bit multiply per lane, the row steps are scalar
@@ -335,7 +343,7 @@ __global__ __launch_bounds__(256) void k_describe(
         for (int i = lane; i < DESC_RAW * DESC_RAW; i += 64) {
             const int r = i / DESC_RAW, c = i - r * DESC_RAW;
             const int gy = reflect101(y0 + r, L.h), gx = reflect101(x0 + c, L.w);
-            S.raw[r * DW_RAW_STRIDE + c] = img[(long long)gy * L.stride + gx];
+            S.buf[r * DW_RAW_STRIDE + c] = img[(long long)gy * L.stride + gx];
         }
     }
     DSYNC();
@@ -349,7 +357,7 @@ __global__ __launch_bounds__(256) void k_describe(
 #pragma unroll
         for (int it = 0; it < 4; it++) {
             const uint4 e = mom[it];   // zero past the last task
-            const uint32_t pix = *reinterpret_cast<const uint32_t *>(&S.raw[e.z]);
+            const uint32_t pix = *reinterpret_cast<const uint32_t *>(&S.buf[e.z]);
             const int sA = (int)__builtin_amdgcn_udot4(pix, e.x, 0u, false);
             const int sB = (int)__builtin_amdgcn_udot4(pix, e.y, 0u, false);
             m10 += sA - 32 * sB;
@@ -375,8 +383,8 @@ __global__ __launch_bounds__(256) void k_describe(
     for (int it = 0; it < 3; it++) {
         const uint32_t te = rtask[it];
         if (te != 0xFFFFFFFFu) {
-            const uint32_t *ra = reinterpret_cast<const uint32_t *>(&S.raw[te & 0xFFFFu]);
-            const uint32_t *rbp = reinterpret_cast<const uint32_t *>(&S.raw[(te & 0xFFFFu) + DW_RAW_STRIDE]);
+            const uint32_t *ra = reinterpret_cast<const uint32_t *>(&S.buf[te & 0xFFFFu]);
+            const uint32_t *rbp = reinterpret_cast<const uint32_t *>(&S.buf[(te & 0xFFFFu) + DW_RAW_STRIDE]);
             const uint32_t a0 = ra[0], a1 = ra[1], a2 = ra[2];
             const uint32_t b0 = rbp[0], b1 = rbp[1], b2 = rbp[2];
             uint32_t o[4];
@@ -394,7 +402,7 @@ __global__ __launch_bounds__(256) void k_describe(
             // (row a | row b << 16), every sum <= 65535: one byte permute per output
             o[0] = __builtin_amdgcn_perm(rb0, ra0, 0x05040100u); o[1] = __builtin_amdgcn_perm(rb1, ra1, 0x05040100u);
             o[2] = __builtin_amdgcn_perm(rb2, ra2, 0x05040100u); o[3] = __builtin_amdgcn_perm(rb3, ra3, 0x05040100u);
-            *reinterpret_cast<uint4 *>(&S.P[te >> 16]) = make_uint4(o[0], o[1], o[2], o[3]);
+            *reinterpret_cast<uint4 *>(&reinterpret_cast<uint32_t *>(S.buf)[te >> 16]) = make_uint4(o[0], o[1], o[2], o[3]);
         }
     }
     DSYNC();
@@ -406,7 +414,7 @@ __global__ __launch_bounds__(256) void k_describe(
     for (int j = 0; j < 4; j++) pf[j] = c_pat_f[j * 64 + lane];
 
     // ---- column pass: lane = (column pair, block of row pairs); 4 x dot2 per output ----
-    uint8_t *bl = S.raw;   // raw is dead from here on
+    uint8_t *bl = S.buf;   // raw is dead from here on; bl grows from byte 0 under the P rows the column pass has finished with
     {
         const uint32_t K01 = k0 | (k1 << 16), K23 = k2 | (k3 << 16), K45 = k2 | (k1 << 16), K6_ = k0;       // even rows
         const uint32_t K_0 = k0 << 16, K12 = k1 | (k2 << 16), K34 = k3 | (k2 << 16), K56 = k1 | (k0 << 16); // odd rows
@@ -417,7 +425,7 @@ __global__ __launch_bounds__(256) void k_describe(
             const uint32_t te = ctask[it];
             if (te != 0xFFFFFFFFu) {
                 const int c = (int)((te >> 21) & 63u);
-                const uint32_t *pin = &S.P[te & 1023u];
+                const uint32_t *pin = &reinterpret_cast<const uint32_t *>(S.buf)[te & 1023u];
                 uint8_t *pout = &bl[(te >> 10) & 2047u];
                 typedef unsigned short us2 __attribute__((ext_vector_type(2)));
                 uint2 w[4];
