@@ -183,11 +183,11 @@ extern "C" int orbx_debug_sincos(const float *h_theta, float *h_cos, float *h_si
     return e == hipSuccess ? ORBX_OK : ORBX_E_HIP;
 }
 
-// One wave per keypoint, four independent waves per workgroup (no workgroup barrier).  LDS per wave:
+// One wave per keypoint, four independent waves per workgroup (no workgroup barrier).  LDS per wave (all three in ONE buffer, below):
 //   raw  44 x 48 B   the 43x43 tile around the keypoint, column 0 at byte 0 (re-aligned at load time)
 //   P    22 x 160 B  row-blurred values, two vertically adjacent rows packed per dword (u16 | u16 << 16)
-//   bl   37 x 40 B   blurred 37x37 (aliases raw, which is dead by then)
-// Row pass: 4 outputs from 3 dword reads with v_alignbyte_b32 windows and v_dot4_u32_u8 (taps are u8).
+//   bl   37 x 40 B   blurred 37x37
+// Row pass: 4 outputs from 3 dword reads, v_dot4_u32_u8 against shifted tap constants (taps are u8).
 // Column pass: the vertical pairs make every output 4 x v_dot2_u32_u16; exact integer sums, one
 // rounding at the end -- identical to row-then-column on u8 -> int32 -> u8 (OpenCV's fixed-point path).
 #define DW_RAW_STRIDE 48
