@@ -43,6 +43,7 @@ __device__ __forceinline__ int block_excl_scan(int v, int *total, int (*wsum)[16
 template <int T>
 struct OctShared {
     int m, prevM, arenaN, lastBase, lastC, nAlive, nE, C, nToExpand, phaseB, done, cutoff, err, firstPass;
+    int w_depth, w_passes, w_mid;   // hand-over of the one-wave passes (oct_body): depth reached, whole passes done, stopped after a pass's first half
     int wsum[2][16];
 };
 
@@ -357,7 +358,7 @@ __device__ __forceinline__ void oct_body(const uint32_t *xy0, const OrbxPlan &pl
         int m = 0;
         for (int i = 0; i < nIni; i++)
             if (cc[i] > 0) listA[m++] = (uint32_t)i;
-        sh.m = m; sh.done = 0; sh.phaseB = 0;
+        sh.m = m; sh.done = 0; sh.phaseB = 0; sh.err = 0;
     }
     __syncthreads();
     OCT_T(1);
@@ -391,7 +392,145 @@ __device__ __forceinline__ void oct_body(const uint32_t *xy0, const OrbxPlan &pl
     OCT_T(2);
     // ---- expansion passes.  Invariant at the top: lnA = node window [lastBase, lastBase+lastC) with slots
     // assigned to its nAlive splittable nodes, cc = their quadrant counts, OWN = node id | quadrant << 30 ----
+#define WSYNC_()                                               \
+    do {                                                       \
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); \
+        __builtin_amdgcn_wave_barrier();                       \
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); \
+    } while (0)
     while (true) {
+        int nE = 0, C = 0;
+        bool half_done = false;        // the first half of this pass (children, survivors) was done by the one-wave passes below
+        // While the passes run on the table (phase A, the next pass's counts come from the table too) they touch a few hundred node
+        // records and no key: as a workgroup pass that is ~12 barrier-separated steps of ~0.3 us for almost no work.  ONE wave
+        // runs them instead -- same arrays, same arithmetic, lanes instead of threads, wave scans instead of workgroup scans, no
+        // barrier (a wave's LDS instructions execute in order) -- while the other waves wait at one barrier.  It stops after the
+        // first half of the first pass it cannot finish alone (the tree is done, phase B begins, or the table ends) and hands the
+        // state over through `sh`; the workgroup finishes that pass below.
+        if (fast && !phaseB && depth + 2 <= D) {
+            if (tid < 64) {
+                const int lane = tid;
+                int passes = 0, mid = 0;
+                for (;;) {
+                    // children per slot and their prefix sums (phase A: every splittable node is expanded)
+                    int carry = 0;
+                    for (int base = 0; base < nAlive; base += 64) {
+                        const int s2 = base + lane;
+                        int ne = 0;
+                        if (s2 < nAlive) ne = (cc[4 * s2] > 0) + (cc[4 * s2 + 1] > 0) + (cc[4 * s2 + 2] > 0) + (cc[4 * s2 + 3] > 0);
+                        const int inc = orbx_wave_incl_scan(ne);
+                        if (s2 < nAlive) childBase[s2] = carry + inc - ne;
+                        carry += __builtin_amdgcn_readlane(inc, 63);
+                    }
+                    nE = nAlive; C = carry;
+                    const int surv = m - nE;
+                    if (arenaN + C > L.arena_cap || C + surv > cap) {
+                        if (lane == 0) { atomicOr(&wk.errflags[f], (uint32_t)ERRF_TREE_OVERFLOW); wk.nk[f * plan.nlevels + l] = 0; sh.err = 1; }
+                        break;
+                    }
+                    WSYNC_();
+                    int myExp = 0;
+                    for (int j0 = 0; j0 < 4 * nE; j0 += 64) {
+                        const int j = j0 + lane;
+                        const bool on = j < 4 * nE;
+                        const int s2 = on ? j >> 2 : 0, q = j & 3;
+                        const uint4 c4 = *reinterpret_cast<const uint4 *>(&cc[4 * s2]);
+                        const int c = (int)(q == 0 ? c4.x : q == 1 ? c4.y : q == 2 ? c4.z : c4.w);
+                        const int r = (q > 0 && c4.x > 0) + (q > 1 && c4.y > 0) + (q > 2 && c4.z > 0);
+                        WSYNC_();
+                        if (on) {
+                            if (c > 0) {
+                                const uint32_t pi = slotNode[s2];
+                                const OrbxNode p = lnA[pi];
+                                const int cidx = childBase[s2] + r;
+                                OrbxNode ch;
+                                oct_child_box(p, q, ch);
+                                ch.count = c;
+                                ch.slot = cidx;
+                                lnB[cidx] = ch;
+                                const uint32_t cp = (pathA[pi] << 2) | (uint32_t)q;
+                                pathB[cidx] = cp;
+                                ftId[fto(depth + 1) + (int)cp] = (uint32_t)(arenaN + cidx);       // depth + 1 <= D here
+                                cc[4 * s2 + q] = (uint32_t)(arenaN + cidx);
+                                nxt[C - 1 - cidx] = (uint32_t)(arenaN + cidx);
+                                myExp += c > 1;
+                            } else {
+                                cc[4 * s2 + q] = 0xFFFFFFFFu;
+                            }
+                        }
+                    }
+                    const int toExpand = __builtin_amdgcn_readlane(orbx_wave_incl_scan(myExp), 63);
+                    WSYNC_();
+                    int scarry = 0;
+                    for (int base = 0; base < m; base += 64) {
+                        const int i = base + lane;
+                        int keep = 0;
+                        uint32_t id = 0;
+                        if (i < m) {
+                            id = cur[i];
+                            keep = 1;
+                            if ((int)id >= lastBase) {
+                                const OrbxNode nd = lnA[id - lastBase];
+                                keep = !(nd.count > 1 && nd.slot < nE);
+                            }
+                        }
+                        const int inc = orbx_wave_incl_scan(keep);
+                        if (keep) nxt[C + scarry + inc - 1] = id;
+                        scarry += __builtin_amdgcn_readlane(inc, 63);
+                    }
+                    const int newM2 = C + scarry;
+                    const bool done2 = newM2 >= N || newM2 == m;
+                    const bool toB = !done2 && newM2 + 3 * toExpand > N;
+                    if (done2 || toB) {                        // the workgroup finishes this pass (and needs nToExpand for its own test)
+                        if (lane == 0) sh.nToExpand = toExpand;
+                        mid = 1;
+                        break;
+                    }
+                    WSYNC_();
+                    // slots of the children that split again, in list order = reverse creation order (phase A)
+                    int na = 0;
+                    for (int base = 0; base < C; base += 64) {
+                        const int j = base + lane;
+                        int cidx = 0, alive = 0;
+                        if (j < C) { cidx = C - 1 - j; alive = lnB[cidx].count > 1; }
+                        const int inc = orbx_wave_incl_scan(alive);
+                        if (alive) { slotNode[na + inc - 1] = (uint32_t)cidx; lnB[cidx].slot = na + inc - 1; }
+                        na += __builtin_amdgcn_readlane(inc, 63);
+                    }
+                    WSYNC_();
+                    // their quadrant counts from the table
+                    const int o2 = fto(depth + 2);
+                    for (int j = lane; j < C; j += 64)
+                        if (lnB[j].count > 1)
+                            for (int q = 0; q < 4; q++) cn[4 * lnB[j].slot + q] = ftCnt[o2 + 4 * (int)pathB[j] + q];
+                    WSYNC_();
+                    m = newM2; lastBase = arenaN; lastC = C; arenaN += C; nAlive = na; depth++; passes++;
+                    { uint32_t *t5 = pathA; pathA = pathB; pathB = t5; }
+                    { uint32_t *t2 = cur; cur = nxt; nxt = t2; }
+                    { OrbxNode *t3 = lnA; lnA = lnB; lnB = t3; }
+                    { uint32_t *t4 = cc; cc = cn; cn = t4; }
+                    if (depth + 2 > D) break;                  // the next pass's counts are not in the table: the keys come in
+                }
+                if (lane == 0) {
+                    sh.m = m; sh.arenaN = arenaN; sh.lastBase = lastBase; sh.lastC = lastC; sh.nAlive = nAlive; sh.w_depth = depth;
+                    sh.w_passes = passes; sh.w_mid = mid; sh.nE = nE; sh.C = C;
+                }
+            }
+            __syncthreads();
+            if (sh.err) return;
+            if (tid >= 64 && (sh.w_passes & 1)) {              // the other waves follow the buffer swaps of the passes they sat out
+                { uint32_t *t5 = pathA; pathA = pathB; pathB = t5; }
+                { uint32_t *t2 = cur; cur = nxt; nxt = t2; }
+                { OrbxNode *t3 = lnA; lnA = lnB; lnB = t3; }
+                { uint32_t *t4 = cc; cc = cn; cn = t4; }
+            }
+            m = sh.m; arenaN = sh.arenaN; lastBase = sh.lastBase; lastC = sh.lastC; nAlive = sh.nAlive; depth = sh.w_depth;
+            half_done = sh.w_mid != 0;
+            nE = sh.nE; C = sh.C;
+            __syncthreads();                                   // sh is read; the pass below may rewrite it
+        }
+        int scarry = 0;
+        if (!half_done) {
         if (tid == 0) { sh.cutoff = 0x7FFFFFFF; sh.nToExpand = 0; }
         __syncthreads();
         // children per slot, prefix sums, phase-B cut-off (:732)
@@ -409,7 +548,7 @@ __device__ __forceinline__ void oct_body(const uint32_t *xy0, const OrbxPlan &pl
             carry += tot;
         }
         __syncthreads();
-        int nE = nAlive, C = carry;
+        nE = nAlive; C = carry;
         if (phaseB && sh.cutoff != 0x7FFFFFFF) {
             nE = sh.cutoff + 1;
             const int s = nE - 1;
@@ -457,7 +596,6 @@ __device__ __forceinline__ void oct_body(const uint32_t *xy0, const OrbxPlan &pl
         }
         if (myExp) atomicAdd(&sh.nToExpand, myExp);
         // survivors keep their relative order behind the new children
-        int scarry = 0;
         for (int base = 0; base < m; base += T) {
             const int i = base + tid;
             int keep = 0;
@@ -474,6 +612,9 @@ __device__ __forceinline__ void oct_body(const uint32_t *xy0, const OrbxPlan &pl
             const int ex = block_excl_scan<T>(keep, &tot, sh.wsum, scanp);
             if (keep) nxt[C + scarry + ex] = id;
             scarry += tot;
+        }
+        } else {
+            scarry = m - nE;       // the one-wave half pass has written the new list already
         }
         __syncthreads();
         OCT_T(4);
