@@ -121,7 +121,7 @@ int orbm_search_for_initialization(orbm_matcher *m, const orbx_keypoint *kps1, c
  *                               mnMinY, mnMaxY;  scale_factors = mvScaleFactors;  u_right = mvuRight or NULL
  *   cur_obs[i2]   in/out: -1 where mvpMapPoints[i2] is NULL, else that point's Observations() (> 0 keeps its place, :1403-1405)
  *   cur_match[i2] out: the last-frame feature whose MapPoint this call put into mvpMapPoints[i2], or -1
- * The projections (cv::Mat algebra = OpenCV's float GEMM: double accumulation, one rounding) run on the host, all windows and
+ * The projections (cv::Mat algebra as cv::gemm's small-matrix path evaluates it: float accumulation, alpha / beta in double) run on the host, all windows and
  * all candidate distances in two GPU passes, and the scan on the host: it is sequential in the reference (an assignment
  * blocks or is overwritten by later ones; *nmatches counts assignments, the rotation cull decrements once per histogram
  * entry, exactly as :1428-1429 and :1458-1462 do).
@@ -153,8 +153,8 @@ int orbm_search_by_projection_map(orbm_matcher *m, int n_mp, const uint8_t *in_v
  * ORBdist = 100, then th = 3, ORBdist = 64).  Three entry points, because the level prediction in the middle belongs to the
  * caller's MapPoint (MapPoint::PredictScale reads the protected mfMaxDistance, src/MapPoint.cc:402-417):
  *   orbm_project_points   (host) :1498-1514 for n world points: x3Dc = Rcw x + tcw, u, v, 1 / zc, the image-bounds test
- *                         (in_image[i], :1507-1510) and dist3D = |x - Ow| -- cv::Mat algebra as OpenCV's float GEMM does it
- *                         (double accumulation, one rounding), cv::norm accumulating in double.  invzc and dist3d may be NULL.
+ *                         (in_image[i], :1507-1510) and dist3D = |x - Ow| -- cv::Mat algebra as cv::gemm's small-matrix path does it
+ *                         (float accumulation, alpha / beta in double), cv::norm accumulating in double.  invzc and dist3d may be NULL.
  *   orbm_predict_scale    (host) MapPoint::PredictScale(dist, Frame*) for callers that own mfMaxDistance themselves.
  *   orbm_search_by_projection_kf   the search: per key-frame MapPoint i, use[i] = usable (non-NULL, !isBad(), not in sAlreadyFound,
  *                         in_image, minDistance <= dist3D <= maxDistance :1492-1521), window (proj_u, proj_v, th *
@@ -220,6 +220,125 @@ int orbm_search_by_bow(orbm_matcher *m,
                        const uint8_t *desc_f, const orbx_keypoint *kps_f, int n_f,
                        const int32_t *fv_f_node, const int32_t *fv_f_off, const int32_t *fv_f_idx, int fv_f_n,
                        float nnratio, int check_orientation, int32_t *match_f, int *nmatches);
+
+/*
+ * ---- the LocalMapping / LoopClosing matchers (include/ORBmatcher.h:60, 66, 72, 77, 80, 83) ----
+ * Same division of labour as the Tracking-thread matchers above: the cv::Mat algebra of a call runs on the host with OpenCV
+ * 3.1.0's arithmetic (3x3 * 3x1 products through cv::gemm's small-matrix path: float accumulation, alpha / beta applied in
+ * double; Mat / scalar as a float multiplication by (float)(1./s); Mat::dot and cv::norm accumulating in double), MapPoint::
+ * PredictScale(dist, pKF) stays with the caller's MapPoint, and the windows (KeyFrame::GetFeaturesInArea, src/KeyFrame.cc:569-606),
+ * the per-candidate predicates and the Hamming distances run on the GPU.  Where the reference's inner loop carries no state from
+ * one MapPoint / feature to the next (Fuse x 2, SearchBySim3, SearchForTriangulation) the selection runs on the GPU as well.
+ *
+ * orbm_reserve       grows the handle's workspace (never shrinks it).  The reference's matcher has no size limit, so every entry
+ *                    point grows the handle when its inputs are larger than the handle instead of refusing; reserving up front
+ *                    keeps allocation out of the calls.  Growing max_train drops the grid in the handle.
+ * orbm_grid_build_kf a KeyFrame's grid: the cells were filled by Frame::PosInGrid with Frame's float mnMinX / mnMinY and grid
+ *                    element sizes (assign_*, inv_*: src/KeyFrame.cc:48-54 copies mGrid), while KeyFrame::GetFeaturesInArea
+ *                    subtracts the key frame's own int mnMinX / mnMinY (query_*: include/KeyFrame.h:190-193).
+ */
+typedef struct {
+    float assign_min_x, assign_min_y;   /* Frame::mnMinX, Frame::mnMinY */
+    float inv_w, inv_h;                 /* pKF->mfGridElementWidthInv, mfGridElementHeightInv */
+    float query_min_x, query_min_y;     /* (float)pKF->mnMinX, (float)pKF->mnMinY */
+} orbm_kf_grid;
+int orbm_reserve(orbm_matcher *m, int max_queries, int max_train, int max_pairs);
+int orbm_grid_build_kf(orbm_matcher *m, const orbx_keypoint *kps_un, int n, float assign_min_x, float assign_min_y,
+                       float inv_w, float inv_h, float query_min_x, float query_min_y);
+
+/* (host) Scw -> [Rcw|tcw] as a row-major 4x4 and Ow: src/ORBmatcher.cc:299-303 == :986-990. */
+int orbm_sim3_decompose(const float *Scw, float *Tcw, float *Ow);
+/* (host) SearchBySim3's src/ORBmatcher.cc:1119-1121: sR12 = s12*R12, sR21 = (1.0/s12)*R12.t(), t21 = -sR21*t12 (row-major 3x3, 3). */
+int orbm_sim3_relative(float s12, const float *R12, const float *t12, float *sR12, float *sR21, float *t21);
+/*
+ * (host) the projection block of :320-355, :852-885, :1008-1043 for n world points: p3Dc = Rcw*p3Dw+tcw, u, v, 1/z, dist3D =
+ * |p3Dw - Ow|.  ok[i] = depth not negative && KeyFrame::IsInImage(u, v) (bounds = the key frame's mnMinX, mnMaxX, mnMinY, mnMaxY;
+ * [min, max), src/KeyFrame.cc:608-611) && (normal == NULL || !(PO.dot(Pn) < 0.5*dist3D)).  Ow == NULL: -Rcw^T tcw; Fuse passes
+ * pKF->GetCameraCenter().  The distance-invariance test and PredictScale are the caller's (MapPoint getters).  invz may be NULL.
+ */
+int orbm_project_points_kf(const float *Tcw, const float *Ow, float fx, float fy, float cx, float cy, const float bounds[4],
+                           const float *xw, const float *normal, int n, float *u, float *v, float *invz, float *dist3d, uint8_t *ok);
+/* (host) SearchBySim3's :1158-1179 / :1238-1259: p = sR*(R_A x + t_A) + t for the MapPoints of key frame A (pose TAw), projected
+ * with pKF1's calibration into key frame B; ok[i] = depth not negative && B->IsInImage(u, v); dist3d = |p|. */
+int orbm_project_points_sim3(const float *TAw, const float *sR, const float *t, float fx, float fy, float cx, float cy,
+                             const float boundsB[4], const float *xw, int n, float *u, float *v, float *dist3d, uint8_t *ok);
+
+/*
+ * ORBmatcher::SearchByProjection(KeyFrame* pKF, cv::Mat Scw, vpPoints, vpMatched, th) (src/ORBmatcher.cc:290-403; LoopClosing.cc:376).
+ * Per candidate MapPoint i: use[i] = every `continue` of :317-355 passed (not bad, not in spAlreadyFound, orbm_project_points_kf's
+ * ok, minDistance <= dist <= maxDistance), proj_u / proj_v, pred_level = pMP->PredictScale(dist, pKF), mp_desc = GetDescriptor().
+ * The key frame's grid must be in the handle (orbm_grid_build_kf).  kf_matched[idx] in/out = (vpMatched[idx] != NULL);
+ * kf_match[idx] out = the MapPoint this call stored in vpMatched[idx], or -1; *nmatches = the return value.  Windows and candidate
+ * distances on the GPU, the scan on the host: a match blocks its slot for every later MapPoint (:375, :396).
+ */
+int orbm_search_by_projection_sim3(orbm_matcher *m, int n_mp, const uint8_t *use, const float *proj_u, const float *proj_v,
+                                   const int32_t *pred_level, const uint8_t *mp_desc, const float *scale_factors, int nlevels,
+                                   const orbx_keypoint *kps_kf, const uint8_t *desc_kf, int n_kf, int th,
+                                   uint8_t *kf_matched, int32_t *kf_match, int *nmatches);
+
+/*
+ * ORBmatcher::SearchByBoW(KeyFrame *pKF1, KeyFrame *pKF2, vpMatches12) (src/ORBmatcher.cc:522-655; LoopClosing.cc:266).
+ * valid1 / valid2 = `pMP && !pMP->isBad()` per feature; kps = mvKeysUn (angles); FeatureVectors as for orbm_search_by_bow.
+ * matches12[idx1] = the feature of KF2 whose MapPoint goes into vpMatches12[idx1], or -1.  Strict `bestDist1 < TH_LOW` (:598).
+ */
+int orbm_search_by_bow_kf(orbm_matcher *m,
+                          const uint8_t *desc1, const orbx_keypoint *kps1, int n1, const uint8_t *valid1,
+                          const int32_t *fv1_node, const int32_t *fv1_off, const int32_t *fv1_idx, int fv1_n,
+                          const uint8_t *desc2, const orbx_keypoint *kps2, int n2, const uint8_t *valid2,
+                          const int32_t *fv2_node, const int32_t *fv2_off, const int32_t *fv2_idx, int fv2_n,
+                          float nnratio, int check_orientation, int32_t *matches12, int *nmatches);
+
+/*
+ * ORBmatcher::SearchForTriangulation(pKF1, pKF2, F12, vMatchedPairs, bOnlyStereo) (src/ORBmatcher.cc:657-823; LocalMapping.cc:270).
+ * has_mp = (GetMapPoint(idx) != NULL), u_right = mvuRight, kps = mvKeysUn; Cw = pKF1->GetCameraCenter(), T2w = pKF2's [R2w|t2w]
+ * (row-major 4x4), the calibration, scale factors and level sigma^2 of pKF2, F12 row-major 3x3.  matches12[idx1] = idx2 or -1:
+ * vMatchedPairs is the list of (i, matches12[i]) with matches12[i] >= 0 in ascending i (:812-820).  Entirely on the GPU (one wave
+ * per feature of KF1): this reference never sets vbMatched2, so no feature's search depends on another's; the candidate accepted
+ * is the last one of minimal distance among those that pass the epipole and epipolar-line tests (:738-755).
+ */
+int orbm_search_for_triangulation(orbm_matcher *m,
+                                  const orbx_keypoint *kps1, const uint8_t *desc1, int n1, const uint8_t *has_mp1, const float *u_right1,
+                                  const int32_t *fv1_node, const int32_t *fv1_off, const int32_t *fv1_idx, int fv1_n,
+                                  const orbx_keypoint *kps2, const uint8_t *desc2, int n2, const uint8_t *has_mp2, const float *u_right2,
+                                  const int32_t *fv2_node, const int32_t *fv2_off, const int32_t *fv2_idx, int fv2_n,
+                                  const float *Cw, const float *T2w, float fx2, float fy2, float cx2, float cy2, const float *F12,
+                                  const float *scale_factors2, const float *level_sigma2_2, int nlevels2, int only_stereo,
+                                  int check_orientation, int32_t *matches12, int *nmatches);
+
+/*
+ * ORBmatcher::Fuse(KeyFrame *pKF, const vector<MapPoint*> &vpMapPoints, th) (src/ORBmatcher.cc:825-975; LocalMapping.cc:491, 516),
+ * the search half (:889-952).  use[i] = every `continue` of :846-885 passed; proj_ur = u - bf*invz (:870); the key frame's grid in
+ * the handle.  best_idx[i] = the key-frame feature the point is fused with (window, octave window, chi-square gate :914-938, best
+ * distance <= TH_LOW), or -1; *nfused = their number.  What happens to a fused point (:954-970: Replace, or AddObservation +
+ * AddMapPoint) is object-graph work and stays with the caller; no MapPoint's search depends on it, so the searches run on the GPU
+ * as one launch.  orbm_fuse_sim3 is Fuse(KeyFrame *pKF, cv::Mat Scw, vpPoints, th, vpReplacePoint) (:977-1100; LoopClosing.cc:600),
+ * :1048-1082: the same without the gate.
+ */
+int orbm_fuse(orbm_matcher *m, int n_mp, const uint8_t *use, const float *proj_u, const float *proj_v, const float *proj_ur,
+              const int32_t *pred_level, const uint8_t *mp_desc, const float *scale_factors, const float *inv_level_sigma2,
+              int nlevels, const orbx_keypoint *kps_kf, const float *u_right_kf, const uint8_t *desc_kf, int n_kf, float th,
+              int32_t *best_idx, int *nfused);
+int orbm_fuse_sim3(orbm_matcher *m, int n_mp, const uint8_t *use, const float *proj_u, const float *proj_v,
+                   const int32_t *pred_level, const uint8_t *mp_desc, const float *scale_factors, int nlevels,
+                   const orbx_keypoint *kps_kf, const uint8_t *desc_kf, int n_kf, float th, int32_t *best_idx, int *nfused);
+
+/*
+ * ORBmatcher::SearchBySim3(pKF1, pKF2, vpMatches12, s12, R12, t12, th) (src/ORBmatcher.cc:1102-1326; LoopClosing.cc:324), the two
+ * searches and the agreement check (:1188-1323).  One MapPoint slot per key-frame feature (n_mp1 == n1, n_mp2 == n2).
+ * use1[i] = pMP && !vbAlreadyMatched1[i] && !isBad() && orbm_project_points_sim3's ok && the distance-invariance test (:1152-1183);
+ * proj_u1 / proj_v1 = its projection into key frame 2, pred_level1 = PredictScale(dist3D, pKF2); use2 / proj_*2 / pred_level2 the
+ * reverse.  Both grids are built by the call (slot 1 of the handle holds key frame 1's afterwards).  match12[i1] = the feature of
+ * KF2 whose MapPoint goes into vpMatches12[i1], or -1; *nfound = the return value.
+ */
+int orbm_search_by_sim3(orbm_matcher *m,
+                        int n_mp1, const uint8_t *use1, const float *proj_u1, const float *proj_v1, const int32_t *pred_level1,
+                        const uint8_t *mp_desc1,
+                        int n_mp2, const uint8_t *use2, const float *proj_u2, const float *proj_v2, const int32_t *pred_level2,
+                        const uint8_t *mp_desc2,
+                        const orbx_keypoint *kps1, const uint8_t *desc1, int n1, const orbm_kf_grid *grid1, const float *scale_factors1,
+                        int nlevels1,
+                        const orbx_keypoint *kps2, const uint8_t *desc2, int n2, const orbm_kf_grid *grid2, const float *scale_factors2,
+                        int nlevels2, float th, int32_t *match12, int *nfound);
 
 /* Host helpers: ComputeThreeMaxima (ind[3], -1 = none) and the histogram cull over match12. */
 int orbm_three_maxima(const int32_t *hist_sizes, int L, int32_t ind[3]);

@@ -184,6 +184,27 @@ def _bind_matcher(L):
     L.orbm_undistort_keypoints.restype = C.c_int
     L.orbm_image_bounds.argtypes = [C.c_int, C.c_int, C.c_float, C.c_float, C.c_float, C.c_float, vp, C.c_int, vp]
     L.orbm_image_bounds.restype = C.c_int
+    f = C.c_float
+    L.orbm_reserve.argtypes = [vp, C.c_int, C.c_int, C.c_int]
+    L.orbm_grid_build_kf.argtypes = [vp, vp, C.c_int, f, f, f, f, f, f]
+    L.orbm_sim3_decompose.argtypes = [vp, vp, vp]
+    L.orbm_sim3_relative.argtypes = [f, vp, vp, vp, vp, vp]
+    L.orbm_project_points_kf.argtypes = [vp, vp, f, f, f, f, vp, vp, vp, C.c_int, vp, vp, vp, vp, vp]
+    L.orbm_project_points_sim3.argtypes = [vp, vp, vp, f, f, f, f, vp, vp, C.c_int, vp, vp, vp, vp]
+    L.orbm_search_by_projection_sim3.argtypes = [vp, C.c_int, vp, vp, vp, vp, vp, vp, C.c_int, vp, vp, C.c_int, C.c_int, vp, vp, vp]
+    L.orbm_search_by_bow_kf.argtypes = [vp, vp, vp, C.c_int, vp, vp, vp, vp, C.c_int,
+                                        vp, vp, C.c_int, vp, vp, vp, vp, C.c_int, f, C.c_int, vp, vp]
+    L.orbm_search_for_triangulation.argtypes = [vp, vp, vp, C.c_int, vp, vp, vp, vp, vp, C.c_int,
+                                                vp, vp, C.c_int, vp, vp, vp, vp, vp, C.c_int,
+                                                vp, vp, f, f, f, f, vp, vp, vp, C.c_int, C.c_int, C.c_int, vp, vp]
+    L.orbm_fuse.argtypes = [vp, C.c_int, vp, vp, vp, vp, vp, vp, vp, vp, C.c_int, vp, vp, vp, C.c_int, f, vp, vp]
+    L.orbm_fuse_sim3.argtypes = [vp, C.c_int, vp, vp, vp, vp, vp, vp, C.c_int, vp, vp, C.c_int, f, vp, vp]
+    L.orbm_search_by_sim3.argtypes = [vp, C.c_int, vp, vp, vp, vp, vp, C.c_int, vp, vp, vp, vp, vp,
+                                      vp, vp, C.c_int, vp, vp, C.c_int, vp, vp, C.c_int, vp, vp, C.c_int, f, vp, vp]
+    for name in ("orbm_reserve", "orbm_grid_build_kf", "orbm_sim3_decompose", "orbm_sim3_relative", "orbm_project_points_kf",
+                 "orbm_project_points_sim3", "orbm_search_by_projection_sim3", "orbm_search_by_bow_kf", "orbm_search_for_triangulation",
+                 "orbm_fuse", "orbm_fuse_sim3", "orbm_search_by_sim3", "orbm_search_by_bow"):
+        getattr(L, name).restype = C.c_int
     L.orbm_last_error.restype = C.c_char_p
     for name in ("orbm_create", "orbm_distance", "orbm_best2", "orbm_distances", "orbm_best2_batch_device",
                  "orbm_match_batch_device", "orbm_rot_filter", "orbm_three_maxima", "orbm_grid_build",
@@ -557,6 +578,144 @@ class ORBmatcher:
                                                   _p(kps_cur), _p(desc_cur), len(kps_cur), th, int(orb_dist), 1 if self.mbCheckOrientation else 0,
                                                   _p(cur_has_point), _p(cm), C.byref(nm)))
         return cm, nm.value
+
+    # ---- the LocalMapping / LoopClosing matchers (include/orbm.h; src/ORBmatcher.cc:290-403, 522-655, 657-823, 825-975, 977-1100, 1102-1326) ----
+    def reserve(self, max_queries=0, max_train=0, max_pairs=0):
+        _mchk(self.L.orbm_reserve(self.h, int(max_queries), int(max_train), int(max_pairs)))
+
+    def grid_build_kf(self, kps_un, grid):
+        """KeyFrame grid: grid = (assign_min_x, assign_min_y, inv_w, inv_h, query_min_x, query_min_y)."""
+        kps_un = np.ascontiguousarray(kps_un)
+        _mchk(self.L.orbm_grid_build_kf(self.h, _p(kps_un), len(kps_un), *[float(v) for v in grid]))
+
+    @staticmethod
+    def Sim3Decompose(Scw):
+        Scw = np.ascontiguousarray(Scw, np.float32).reshape(16)
+        T, Ow = np.zeros(16, np.float32), np.zeros(3, np.float32)
+        _mchk(lib().orbm_sim3_decompose(_p(Scw), _p(T), _p(Ow)))
+        return T.reshape(4, 4), Ow
+
+    @staticmethod
+    def Sim3Relative(s12, R12, t12):
+        R12 = np.ascontiguousarray(R12, np.float32).reshape(9); t12 = np.ascontiguousarray(t12, np.float32).reshape(3)
+        sR12, sR21, t21 = np.zeros(9, np.float32), np.zeros(9, np.float32), np.zeros(3, np.float32)
+        _mchk(lib().orbm_sim3_relative(C.c_float(s12), _p(R12), _p(t12), _p(sR12), _p(sR21), _p(t21)))
+        return sR12.reshape(3, 3), sR21.reshape(3, 3), t21
+
+    @staticmethod
+    def ProjectPointsKF(Tcw, K, bounds, xw, normal=None, Ow=None):
+        """orbm_project_points_kf: (u, v, invz, dist3D, ok)."""
+        Tcw = np.ascontiguousarray(Tcw, np.float32).reshape(16); b = np.ascontiguousarray(bounds, np.float32)
+        xw = np.ascontiguousarray(xw, np.float32).reshape(-1, 3)
+        if normal is not None:
+            normal = np.ascontiguousarray(normal, np.float32).reshape(-1, 3)
+        if Ow is not None:
+            Ow = np.ascontiguousarray(Ow, np.float32).reshape(3)
+        n = len(xw)
+        u, v, iz, d3 = (np.zeros(n, np.float32) for _ in range(4))
+        ok = np.zeros(n, np.uint8)
+        fx, fy, cx, cy = K
+        _mchk(lib().orbm_project_points_kf(_p(Tcw), _p(Ow), fx, fy, cx, cy, _p(b), _p(xw), _p(normal), n, _p(u), _p(v), _p(iz), _p(d3), _p(ok)))
+        return u, v, iz, d3, ok
+
+    @staticmethod
+    def ProjectPointsSim3(TAw, sR, t, K, boundsB, xw):
+        TAw = np.ascontiguousarray(TAw, np.float32).reshape(16); sR = np.ascontiguousarray(sR, np.float32).reshape(9)
+        t = np.ascontiguousarray(t, np.float32).reshape(3); b = np.ascontiguousarray(boundsB, np.float32)
+        xw = np.ascontiguousarray(xw, np.float32).reshape(-1, 3)
+        n = len(xw)
+        u, v, d3 = (np.zeros(n, np.float32) for _ in range(3))
+        ok = np.zeros(n, np.uint8)
+        fx, fy, cx, cy = K
+        _mchk(lib().orbm_project_points_sim3(_p(TAw), _p(sR), _p(t), fx, fy, cx, cy, _p(b), _p(xw), n, _p(u), _p(v), _p(d3), _p(ok)))
+        return u, v, d3, ok
+
+    def SearchByProjectionSim3(self, use, proj_u, proj_v, pred_level, mp_desc, scale_factors, kps_kf, desc_kf, kf_matched, th):
+        """SearchByProjection(KeyFrame*, Scw, vpPoints, vpMatched, th) after the projection step.  kf_matched uint8 in/out.
+        Returns (kf_match, nmatches)."""
+        f32 = lambda a: np.ascontiguousarray(a, np.float32)
+        use = np.ascontiguousarray(use, np.uint8); pu, pv, sf = f32(proj_u), f32(proj_v), f32(scale_factors)
+        lv = np.ascontiguousarray(pred_level, np.int32); mp_desc = np.ascontiguousarray(mp_desc, np.uint8).reshape(-1, 32)
+        kps_kf = np.ascontiguousarray(kps_kf); desc_kf = np.ascontiguousarray(desc_kf, np.uint8).reshape(-1, 32)
+        assert kf_matched.dtype == np.uint8 and kf_matched.flags["C_CONTIGUOUS"] and len(kf_matched) == len(kps_kf)
+        km = np.full(len(kps_kf), -1, np.int32)
+        nm = C.c_int(0)
+        _mchk(self.L.orbm_search_by_projection_sim3(self.h, len(use), _p(use), _p(pu), _p(pv), _p(lv), _p(mp_desc), _p(sf), len(sf), _p(kps_kf),
+                                                    _p(desc_kf), len(kps_kf), int(th), _p(kf_matched), _p(km), C.byref(nm)))
+        return km, nm.value
+
+    def SearchByBoWKF(self, kps1, desc1, featvec1, valid1, kps2, desc2, featvec2, valid2):
+        """SearchByBoW(KeyFrame*, KeyFrame*, vpMatches12): returns (matches12, nmatches)."""
+        desc1 = np.ascontiguousarray(desc1, np.uint8).reshape(-1, 32); desc2 = np.ascontiguousarray(desc2, np.uint8).reshape(-1, 32)
+        kps1 = np.ascontiguousarray(kps1); kps2 = np.ascontiguousarray(kps2)
+        n1, o1, i1 = [np.ascontiguousarray(a, np.int32) for a in featvec1]
+        n2, o2, i2 = [np.ascontiguousarray(a, np.int32) for a in featvec2]
+        valid1 = np.ascontiguousarray(valid1, np.uint8); valid2 = np.ascontiguousarray(valid2, np.uint8)
+        m12 = np.full(len(desc1), -1, np.int32)
+        nm = C.c_int(0)
+        _mchk(self.L.orbm_search_by_bow_kf(self.h, _p(desc1), _p(kps1), len(desc1), _p(valid1), _p(n1), _p(o1), _p(i1), len(n1),
+                                           _p(desc2), _p(kps2), len(desc2), _p(valid2), _p(n2), _p(o2), _p(i2), len(n2),
+                                           C.c_float(self.mfNNratio), 1 if self.mbCheckOrientation else 0, _p(m12), C.byref(nm)))
+        return m12, nm.value
+
+    def SearchForTriangulation(self, kps1, desc1, has_mp1, u_right1, featvec1, kps2, desc2, has_mp2, u_right2, featvec2,
+                               Cw, T2w, K2, F12, scale_factors2, level_sigma2_2, only_stereo=False):
+        """SearchForTriangulation(pKF1, pKF2, F12, vMatchedPairs, bOnlyStereo): returns (matches12, nmatches)."""
+        f32 = lambda a: np.ascontiguousarray(a, np.float32)
+        desc1 = np.ascontiguousarray(desc1, np.uint8).reshape(-1, 32); desc2 = np.ascontiguousarray(desc2, np.uint8).reshape(-1, 32)
+        kps1 = np.ascontiguousarray(kps1); kps2 = np.ascontiguousarray(kps2)
+        n1, o1, i1 = [np.ascontiguousarray(a, np.int32) for a in featvec1]
+        n2, o2, i2 = [np.ascontiguousarray(a, np.int32) for a in featvec2]
+        h1 = np.ascontiguousarray(has_mp1, np.uint8); h2 = np.ascontiguousarray(has_mp2, np.uint8)
+        ur1, ur2, Cw, T2w, F12, sf2, ls2 = f32(u_right1), f32(u_right2), f32(Cw).reshape(3), f32(T2w).reshape(16), f32(F12).reshape(9), f32(scale_factors2), f32(level_sigma2_2)
+        m12 = np.full(len(desc1), -1, np.int32)
+        nm = C.c_int(0)
+        fx, fy, cx, cy = K2
+        _mchk(self.L.orbm_search_for_triangulation(self.h, _p(kps1), _p(desc1), len(desc1), _p(h1), _p(ur1), _p(n1), _p(o1), _p(i1), len(n1),
+                                                   _p(kps2), _p(desc2), len(desc2), _p(h2), _p(ur2), _p(n2), _p(o2), _p(i2), len(n2),
+                                                   _p(Cw), _p(T2w), fx, fy, cx, cy, _p(F12), _p(sf2), _p(ls2), len(sf2), 1 if only_stereo else 0,
+                                                   1 if self.mbCheckOrientation else 0, _p(m12), C.byref(nm)))
+        return m12, nm.value
+
+    def Fuse(self, use, proj_u, proj_v, proj_ur, pred_level, mp_desc, scale_factors, inv_level_sigma2, kps_kf, u_right_kf, desc_kf, th=3.0):
+        """Fuse(KeyFrame*, vpMapPoints, th), the search half: returns (best_idx, nfused)."""
+        f32 = lambda a: np.ascontiguousarray(a, np.float32)
+        use = np.ascontiguousarray(use, np.uint8); pu, pv, pr, sf, inv, urk = f32(proj_u), f32(proj_v), f32(proj_ur), f32(scale_factors), f32(inv_level_sigma2), f32(u_right_kf)
+        lv = np.ascontiguousarray(pred_level, np.int32); mp_desc = np.ascontiguousarray(mp_desc, np.uint8).reshape(-1, 32)
+        kps_kf = np.ascontiguousarray(kps_kf); desc_kf = np.ascontiguousarray(desc_kf, np.uint8).reshape(-1, 32)
+        bi = np.full(len(use), -1, np.int32)
+        nf = C.c_int(0)
+        _mchk(self.L.orbm_fuse(self.h, len(use), _p(use), _p(pu), _p(pv), _p(pr), _p(lv), _p(mp_desc), _p(sf), _p(inv), len(sf), _p(kps_kf), _p(urk),
+                               _p(desc_kf), len(kps_kf), C.c_float(th), _p(bi), C.byref(nf)))
+        return bi, nf.value
+
+    def FuseSim3(self, use, proj_u, proj_v, pred_level, mp_desc, scale_factors, kps_kf, desc_kf, th):
+        """Fuse(KeyFrame*, Scw, vpPoints, th, vpReplacePoint), the search half: returns (best_idx, nfused)."""
+        f32 = lambda a: np.ascontiguousarray(a, np.float32)
+        use = np.ascontiguousarray(use, np.uint8); pu, pv, sf = f32(proj_u), f32(proj_v), f32(scale_factors)
+        lv = np.ascontiguousarray(pred_level, np.int32); mp_desc = np.ascontiguousarray(mp_desc, np.uint8).reshape(-1, 32)
+        kps_kf = np.ascontiguousarray(kps_kf); desc_kf = np.ascontiguousarray(desc_kf, np.uint8).reshape(-1, 32)
+        bi = np.full(len(use), -1, np.int32)
+        nf = C.c_int(0)
+        _mchk(self.L.orbm_fuse_sim3(self.h, len(use), _p(use), _p(pu), _p(pv), _p(lv), _p(mp_desc), _p(sf), len(sf), _p(kps_kf), _p(desc_kf), len(kps_kf),
+                                    C.c_float(th), _p(bi), C.byref(nf)))
+        return bi, nf.value
+
+    def SearchBySim3(self, use1, u1, v1, lv1, mp_desc1, use2, u2, v2, lv2, mp_desc2, kps1, desc1, grid1, sf1, kps2, desc2, grid2, sf2, th):
+        """SearchBySim3, the two searches and the agreement check: returns (match12, nfound).  grid1 / grid2 as for grid_build_kf."""
+        f32 = lambda a: np.ascontiguousarray(a, np.float32)
+        u8 = lambda a: np.ascontiguousarray(a, np.uint8)
+        i32 = lambda a: np.ascontiguousarray(a, np.int32)
+        use1, use2, u1, v1, u2, v2, lv1, lv2, sf1, sf2 = u8(use1), u8(use2), f32(u1), f32(v1), f32(u2), f32(v2), i32(lv1), i32(lv2), f32(sf1), f32(sf2)
+        mp_desc1 = u8(mp_desc1).reshape(-1, 32); mp_desc2 = u8(mp_desc2).reshape(-1, 32)
+        kps1 = np.ascontiguousarray(kps1); kps2 = np.ascontiguousarray(kps2); desc1 = u8(desc1).reshape(-1, 32); desc2 = u8(desc2).reshape(-1, 32)
+        g1, g2 = f32(grid1), f32(grid2)
+        m12 = np.full(len(use1), -1, np.int32)
+        nf = C.c_int(0)
+        _mchk(self.L.orbm_search_by_sim3(self.h, len(use1), _p(use1), _p(u1), _p(v1), _p(lv1), _p(mp_desc1), len(use2), _p(use2), _p(u2), _p(v2), _p(lv2),
+                                         _p(mp_desc2), _p(kps1), _p(desc1), len(kps1), _p(g1), _p(sf1), len(sf1), _p(kps2), _p(desc2), len(kps2), _p(g2),
+                                         _p(sf2), len(sf2), C.c_float(th), _p(m12), C.byref(nf)))
+        return m12, nf.value
 
     def SearchForInitialization(self, kps1, desc1, kps2, desc2, prev_matched, windowSize=10):
         """ORBmatcher::SearchForInitialization(F1, F2, vbPrevMatched, vnMatches12, windowSize) (src/ORBmatcher.cc:405-520).

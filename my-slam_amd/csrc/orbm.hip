@@ -443,8 +443,8 @@ extern "C" void orbm_destroy(orbm_matcher *m)
     (void)hipSetDevice(m->device);
     (void)hipFree(m->d_q); (void)hipFree(m->d_t); (void)hipFree(m->d_off); (void)hipFree(m->d_idx);
     (void)hipFree(m->d_out); (void)hipFree(m->d_part);
-    (void)hipFree(m->grid.kx); (void)hipFree(m->grid.ky); (void)hipFree(m->grid.koct); (void)hipFree(m->grid.cell_start);
-    (void)hipFree(m->grid.items); (void)hipFree(m->grid.cell_of); (void)hipFree(m->d_qf); (void)hipFree(m->d_qi); (void)hipFree(m->d_skip);
+    orbm_grid_free(m->grid); orbm_grid_free(m->grid2);
+    (void)hipFree(m->d_qf); (void)hipFree(m->d_qi); (void)hipFree(m->d_skip);
     if (m->stream) (void)hipStreamDestroy(m->stream);
     (void)hipHostFree(m->h_pin); (void)hipHostFree(m->arena); (void)hipFree(m->d_arena);
     delete m;
@@ -476,13 +476,59 @@ extern "C" int orbm_create(orbm_matcher **out, int device, int max_queries, int 
     return ORBX_OK;
 }
 
+void orbm_grid_free(OrbmGrid &g)
+{
+    (void)hipFree(g.kx); (void)hipFree(g.ky); (void)hipFree(g.koct); (void)hipFree(g.cell_start); (void)hipFree(g.items); (void)hipFree(g.cell_of);
+    g.kx = g.ky = nullptr; g.koct = g.cell_start = g.items = g.cell_of = nullptr;
+}
+
+// Grows the workspace (never shrinks it).  The reference's matcher has no size limit (it works on std::vectors), so every entry
+// point that finds its inputs larger than the handle grows the handle instead of refusing; a caller that knows its sizes calls this
+// once up front and no call allocates.  Growing max_train drops the Frame grid in the handle (orbm_grid_build again).
+extern "C" int orbm_reserve(orbm_matcher *m, int max_queries, int max_train, int max_pairs)
+{
+    if (!m) return mfail(ORBX_E_INVALID, "NULL handle");
+    const int nq = std::max(m->max_q, max_queries), nt = std::max(m->max_t, max_train), np = std::max(m->max_pairs, max_pairs);
+    if (nq == m->max_q && nt == m->max_t && np == m->max_pairs) return ORBX_OK;
+    MHIPCHK(hipSetDevice(m->device));
+    MHIPCHK(hipStreamSynchronize(m->stream));
+    if (nq > m->max_q) {
+        (void)hipFree(m->d_q); (void)hipFree(m->d_off); m->d_q = nullptr; m->d_off = nullptr;
+        MHIPCHK(hipMalloc((void **)&m->d_q, (size_t)nq * 32));
+        MHIPCHK(hipMalloc((void **)&m->d_off, ((size_t)nq + 1) * 4));
+    }
+    if (nt > m->max_t) {
+        (void)hipFree(m->d_t); m->d_t = nullptr;
+        MHIPCHK(hipMalloc((void **)&m->d_t, (size_t)nt * 32));
+        orbm_grid_free(m->grid); orbm_grid_free(m->grid2); m->grid_ok = false; m->grid2_ok = false;     // sized by max_train
+        (void)hipFree(m->d_skip); m->d_skip = nullptr;
+    }
+    if (np > m->max_pairs) {
+        (void)hipFree(m->d_idx); m->d_idx = nullptr;
+        MHIPCHK(hipMalloc((void **)&m->d_idx, std::max<size_t>((size_t)np, 1) * 4));
+    }
+    const size_t out_old = std::max<size_t>((size_t)3 * m->max_q, (size_t)m->max_pairs), out_new = std::max<size_t>((size_t)3 * nq, (size_t)np);
+    if (out_new > out_old) {
+        (void)hipFree(m->d_out); m->d_out = nullptr;
+        MHIPCHK(hipMalloc((void **)&m->d_out, out_new * 4));
+    }
+    m->max_q = nq; m->max_t = nt; m->max_pairs = np;
+    return ORBX_OK;
+}
+int orbm_grow(orbm_matcher *m, long long need_q, long long need_t, long long need_pairs)
+{
+    if (need_q > (1ll << 28) || need_t > (1ll << 28) || need_pairs > (1ll << 30)) return mfail(ORBX_E_CAPACITY, "request beyond 2^28 descriptors / 2^30 pairs");
+    auto up = [](long long need, int have) { return need > have ? (int)std::min<long long>(need + need / 2, 1ll << 30) : have; };
+    return orbm_reserve(m, up(need_q, m->max_q), up(need_t, m->max_t), up(need_pairs, m->max_pairs));
+}
+
 static int check_csr(const int32_t *off, const int32_t *idx, int nq, int nt, int max_pairs, int *total)
 {
     if (off[0] != 0) return mfail(ORBX_E_INVALID, "cand_off[0] must be 0");
     for (int i = 0; i < nq; i++)
         if (off[i + 1] < off[i]) return mfail(ORBX_E_INVALID, "cand_off not monotone at %d", i);
     *total = off[nq];
-    if (*total > max_pairs) return mfail(ORBX_E_CAPACITY, "%d candidate pairs, matcher sized for %d", *total, max_pairs);
+    (void)max_pairs;
     if (*total > 0 && !idx) return mfail(ORBX_E_INVALID, "cand_idx is NULL");
     for (int c = 0; c < *total; c++)
         if (idx[c] < 0 || idx[c] >= nt) return mfail(ORBX_E_INVALID, "cand_idx[%d]=%d outside [0,%d)", c, idx[c], nt);
@@ -517,7 +563,8 @@ extern "C" int orbm_best2(orbm_matcher *m, const uint8_t *q, int nq, const uint8
                           int32_t *best_idx, int32_t *best_d, int32_t *second_d)
 {
     if (!m) return mfail(ORBX_E_INVALID, "NULL handle");
-    if (nq < 0 || nt < 0 || nq > m->max_q || nt > m->max_t) return mfail(ORBX_E_CAPACITY, "nq=%d nt=%d exceed matcher sizes %d/%d", nq, nt, m->max_q, m->max_t);
+    if (nq < 0 || nt < 0) return mfail(ORBX_E_INVALID, "nq=%d nt=%d", nq, nt);
+    { int rc_ = orbm_grow(m, nq, nt, cand_off && nq > 0 ? cand_off[nq] : 0); if (rc_ != ORBX_OK) return rc_; }
     if (nq == 0) return ORBX_OK;
     if (!q || !best_idx || !best_d || !second_d || (nt > 0 && !t)) return mfail(ORBX_E_INVALID, "NULL buffer");
     MHIPCHK(hipSetDevice(m->device));
@@ -556,7 +603,8 @@ extern "C" int orbm_distances(orbm_matcher *m, const uint8_t *q, int nq, const u
                               const int32_t *cand_off, const int32_t *cand_idx, int32_t *dist)
 {
     if (!m) return mfail(ORBX_E_INVALID, "NULL handle");
-    if (nq < 0 || nt < 0 || nq > m->max_q || nt > m->max_t) return mfail(ORBX_E_CAPACITY, "nq=%d nt=%d exceed matcher sizes", nq, nt);
+    if (nq < 0 || nt < 0) return mfail(ORBX_E_INVALID, "nq=%d nt=%d", nq, nt);
+    { int rc_ = orbm_grow(m, nq, nt, cand_off && nq > 0 ? cand_off[nq] : (long long)nq * nt); if (rc_ != ORBX_OK) return rc_; }
     if (nq == 0 || nt == 0) return ORBX_OK;
     if (!q || !t || !dist) return mfail(ORBX_E_INVALID, "NULL buffer");
     MHIPCHK(hipSetDevice(m->device));
@@ -671,23 +719,10 @@ extern "C" int orbm_best2_batch_device(orbm_matcher *m, const uint8_t *d_q, cons
 #define BOW_MAX_NODE_FEATURES 4096      // 64 chunks of 64 lanes
 #define BOW_REG_CHUNKS 4                // frame features 0..255 of a node stay in registers
 
-// wave-wide minimum, every lane gets it: butterfly inside each row of 16 lanes with DPP (quad swaps, half-row and row mirror),
-// then the four row results through v_readlane.  ~10 instructions; six ds_bpermute steps are several hundred cycles.
-__device__ __forceinline__ uint32_t wave_min_u32(uint32_t v)
-{
-    v = min(v, (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, 0xB1, 0xf, 0xf, false));     // quad_perm [1,0,3,2]
-    v = min(v, (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x4E, 0xf, 0xf, false));     // quad_perm [2,3,0,1]
-    v = min(v, (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x141, 0xf, 0xf, false));    // row_half_mirror
-    v = min(v, (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x140, 0xf, 0xf, false));    // row_mirror
-    const uint32_t r0 = (uint32_t)__builtin_amdgcn_readlane((int)v, 0), r1 = (uint32_t)__builtin_amdgcn_readlane((int)v, 16);
-    const uint32_t r2 = (uint32_t)__builtin_amdgcn_readlane((int)v, 32), r3 = (uint32_t)__builtin_amdgcn_readlane((int)v, 48);
-    return min(min(r0, r1), min(r2, r3));
-}
-
 __global__ __launch_bounds__(M_THREADS) void k_bow_select(
     const uint8_t *__restrict__ q, const uint8_t *__restrict__ t, const int32_t *__restrict__ kf_idx,
     const int32_t *__restrict__ f_idx, const int4 *__restrict__ pairs, int npairs, const uint8_t *__restrict__ valid,
-    float nnratio, int32_t *__restrict__ match_f)
+    float nnratio, int th, int32_t *__restrict__ match_f)
 {
     // the serial loop over a node's key-frame features must not wait for global memory: their descriptors are staged in LDS
     // 64 at a time (lane j fetches feature j), and the first 256 frame features of the node stay in registers
@@ -746,7 +781,7 @@ __global__ __launch_bounds__(M_THREADS) void k_bow_select(
             const uint32_t B = wave_min_u32(bk);
             const uint32_t S2 = wave_min_u32((bk == B) ? sk : bk);   // the winner's position is unique: every other lane offers its best
             const int best1 = (int)(B >> 16), best2 = (int)(S2 >> 16);
-            if (best1 <= ORBM_TH_LOW && (float)best1 < __fmul_rn(nnratio, (float)best2)) {     // :228-232
+            if (best1 <= th && (float)best1 < __fmul_rn(nnratio, (float)best2)) {     // :228-232 (th = TH_LOW), :598-600 (th = TH_LOW - 1)
                 const int pos = (int)(B & 0xFFFFu);
                 if (lane == (pos & 63)) {
                     taken |= 1ull << (pos >> 6);
@@ -796,7 +831,7 @@ static int search_by_bow_device(orbm_matcher *m,
                                 const int32_t *fv_kf_node, const int32_t *fv_kf_off, const int32_t *fv_kf_idx, int fv_kf_n,
                                 const uint8_t *desc_f, const orbx_keypoint *kps_f, int n_f,
                                 const int32_t *fv_f_node, const int32_t *fv_f_off, const int32_t *fv_f_idx, int fv_f_n,
-                                float nnratio, int check_orientation, int32_t *match_f, int *nmatches)
+                                float nnratio, int th, int check_orientation, int32_t *match_f, int *nmatches)
 {
     static const bool force_host = [] { const char *e = getenv("ORBM_BOW_HOST_SELECT"); return e && e[0] == '1'; }();
     if (force_host) return 1;
@@ -837,7 +872,7 @@ static int search_by_bow_device(orbm_matcher *m,
             rc_ = orbm_flush_in(m, mark, s);
             if (rc_ != ORBX_OK) return rc_;
             hipLaunchKernelGGL(k_bow_select, dim3((np + M_THREADS / 64 - 1) / (M_THREADS / 64)), dim3(M_THREADS), 0, s,
-                               dq, dt, dki, dfi, dp, np, dv, nnratio, m->d_out);
+                               dq, dt, dki, dfi, dp, np, dv, nnratio, th, m->d_out);
             MHIPCHK(hipGetLastError());
             const int32_t *out = (const int32_t *)orbm_d2h_tmp(m, m->d_out, (size_t)n_f * 4, s);
             if (out) {
@@ -870,7 +905,7 @@ static int search_by_bow_device(orbm_matcher *m,
     MHIPCHK(hipMemsetAsync(m->d_out, 0xFF, (size_t)n_f * 4, s));        // match table = -1
     hipLaunchKernelGGL(k_bow_select, dim3((np + M_THREADS / 64 - 1) / (M_THREADS / 64)), dim3(M_THREADS), 0, s,
                        m->d_q, m->d_t, m->d_idx + i_kf, m->d_idx + i_f, reinterpret_cast<const int4 *>(m->d_idx + i_pairs), np,
-                       valid_kf ? reinterpret_cast<const uint8_t *>(m->d_idx + i_valid) : (const uint8_t *)nullptr, nnratio, m->d_out);
+                       valid_kf ? reinterpret_cast<const uint8_t *>(m->d_idx + i_valid) : (const uint8_t *)nullptr, nnratio, th, m->d_out);
     MHIPCHK(hipGetLastError());
     MHIPCHK(hipMemcpyAsync(m->h_pin + o_m, m->d_out, (size_t)n_f * 4, hipMemcpyDeviceToHost, s));
     MHIPCHK(hipStreamSynchronize(s));
@@ -880,12 +915,12 @@ static int search_by_bow_device(orbm_matcher *m,
 
 // ---- N2: SearchByBoW (src/ORBmatcher.cc:159-288).  Usual path: search_by_bow_device above (selection on the GPU).  The rest
 // of this function is the general fallback: every node-mate distance on the GPU, the order-dependent selection on the host ----
-extern "C" int orbm_search_by_bow(orbm_matcher *m,
-                                  const uint8_t *desc_kf, const orbx_keypoint *kps_kf, int n_kf, const uint8_t *valid_kf,
-                                  const int32_t *fv_kf_node, const int32_t *fv_kf_off, const int32_t *fv_kf_idx, int fv_kf_n,
-                                  const uint8_t *desc_f, const orbx_keypoint *kps_f, int n_f,
-                                  const int32_t *fv_f_node, const int32_t *fv_f_off, const int32_t *fv_f_idx, int fv_f_n,
-                                  float nnratio, int check_orientation, int32_t *match_f, int *nmatches)
+static int search_by_bow_impl(orbm_matcher *m,
+                              const uint8_t *desc_kf, const orbx_keypoint *kps_kf, int n_kf, const uint8_t *valid_kf,
+                              const int32_t *fv_kf_node, const int32_t *fv_kf_off, const int32_t *fv_kf_idx, int fv_kf_n,
+                              const uint8_t *desc_f, const orbx_keypoint *kps_f, int n_f,
+                              const int32_t *fv_f_node, const int32_t *fv_f_off, const int32_t *fv_f_idx, int fv_f_n,
+                              float nnratio, int th, int check_orientation, int32_t *match_f, int *nmatches)
 {
     if (!m) return mfail(ORBX_E_INVALID, "NULL handle");
     if (n_kf < 0 || n_f < 0 || fv_kf_n < 0 || fv_f_n < 0 || !match_f || !nmatches) return mfail(ORBX_E_INVALID, "bad argument");
@@ -894,10 +929,10 @@ extern "C" int orbm_search_by_bow(orbm_matcher *m,
     if (n_kf == 0 || n_f == 0 || fv_kf_n == 0 || fv_f_n == 0) return ORBX_OK;
     if (!desc_kf || !kps_kf || !desc_f || !kps_f || !fv_kf_node || !fv_kf_off || !fv_kf_idx || !fv_f_node || !fv_f_off || !fv_f_idx)
         return mfail(ORBX_E_INVALID, "NULL buffer");
-    if (n_f > m->max_t) return mfail(ORBX_E_CAPACITY, "n_f=%d exceeds the matcher's max_train=%d", n_f, m->max_t);
+    { int rc_ = orbm_grow(m, n_kf, n_f, 0); if (rc_ != ORBX_OK) return rc_; }
     {   // selection on the GPU when every matched node fits a wave's registers and the staging fits the handle's buffers
         int rc = search_by_bow_device(m, desc_kf, kps_kf, n_kf, valid_kf, fv_kf_node, fv_kf_off, fv_kf_idx, fv_kf_n, desc_f, kps_f, n_f,
-                                      fv_f_node, fv_f_off, fv_f_idx, fv_f_n, nnratio, check_orientation, match_f, nmatches);
+                                      fv_f_node, fv_f_off, fv_f_idx, fv_f_n, nnratio, th, check_orientation, match_f, nmatches);
         if (rc != 1) return rc;    // 1 = not applicable: distances on the GPU, selection on the host (below)
     }
     // merge-join of the two ascending node lists (:178-262); queries = usable key-frame features in visiting order
@@ -924,13 +959,13 @@ extern "C" int orbm_search_by_bow(orbm_matcher *m,
     }
     const int nq = (int)qs.size();
     if (nq == 0 || pairs == 0) return ORBX_OK;
-    if (pairs > m->max_pairs) return mfail(ORBX_E_CAPACITY, "%lld candidate pairs, matcher sized for %d", pairs, m->max_pairs);
+    { int rc_ = orbm_grow(m, 0, 0, pairs); if (rc_ != ORBX_OK) return rc_; }
     // Usual case (both frames below 65536 features): the key frame's descriptor block goes up as it is and every pair is
     // (key-frame feature << 16 | frame feature).  Otherwise the query descriptors are compacted and the kernel finds a
     // pair's query by binary search over the offsets.
     const bool packed16 = n_kf < 65536 && n_f < 65536;
     const int nq_up = packed16 ? n_kf : nq;
-    if (nq_up > m->max_q) return mfail(ORBX_E_CAPACITY, "%d key-frame descriptors, matcher sized for %d queries", nq_up, m->max_q);
+    { int rc_ = orbm_grow(m, nq_up, 0, 0); if (rc_ != ORBX_OK) return rc_; }
     // pinned staging block: [query descriptors | n_f x 32 frame descriptors | nq+1 offsets | pairs indices | pairs distances]
     MHIPCHK(hipSetDevice(m->device));
     hipStream_t s = m->stream;
@@ -986,7 +1021,7 @@ extern "C" int orbm_search_by_bow(orbm_matcher *m,
             if (d < best1) { best2 = best1; best1 = d; bestF = fi; }
             else if (d < best2) best2 = d;
         }
-        if (best1 <= ORBM_TH_LOW && (float)best1 < nnratio * (float)best2) {
+        if (best1 <= th && (float)best1 < nnratio * (float)best2) {
             match_f[bestF] = qs[i].kf;
             if (check_orientation) {
                 float rot = kps_kf[qs[i].kf].angle - kps_f[bestF].angle;
@@ -1007,6 +1042,56 @@ extern "C" int orbm_search_by_bow(orbm_matcher *m,
             if (bin_of[i] >= 0 && bin_of[i] != ind[0] && bin_of[i] != ind[1] && bin_of[i] != ind[2]) { match_f[i] = -1; nm--; }
     }
     *nmatches = nm;
+    return ORBX_OK;
+}
+
+extern "C" int orbm_search_by_bow(orbm_matcher *m,
+                                  const uint8_t *desc_kf, const orbx_keypoint *kps_kf, int n_kf, const uint8_t *valid_kf,
+                                  const int32_t *fv_kf_node, const int32_t *fv_kf_off, const int32_t *fv_kf_idx, int fv_kf_n,
+                                  const uint8_t *desc_f, const orbx_keypoint *kps_f, int n_f,
+                                  const int32_t *fv_f_node, const int32_t *fv_f_off, const int32_t *fv_f_idx, int fv_f_n,
+                                  float nnratio, int check_orientation, int32_t *match_f, int *nmatches)
+{
+    return search_by_bow_impl(m, desc_kf, kps_kf, n_kf, valid_kf, fv_kf_node, fv_kf_off, fv_kf_idx, fv_kf_n, desc_f, kps_f, n_f,
+                              fv_f_node, fv_f_off, fv_f_idx, fv_f_n, nnratio, ORBM_TH_LOW, check_orientation, match_f, nmatches);
+}
+
+// ---- ORBmatcher::SearchByBoW(KeyFrame *pKF1, KeyFrame *pKF2, vpMatches12) (src/ORBmatcher.cc:522-655) ----
+// The same node-by-node scan as the key-frame / frame variant above with three differences: features of BOTH key frames need a
+// usable MapPoint (:558-562, :576-580), the acceptance is the strict `bestDist1 < TH_LOW` (:598), and the table is indexed by the
+// OUTER key frame's features (vpMatches12[idx1]).  A feature of KF2 that can never be taken (no MapPoint, bad MapPoint) is dropped
+// from KF2's node lists before the scan -- skipping it inside the scan is the same thing --, the scan runs with th = TH_LOW - 1,
+// and the table it returns (inner feature -> outer feature, one-to-one by vbMatched2) is inverted.
+extern "C" int orbm_search_by_bow_kf(orbm_matcher *m,
+                                     const uint8_t *desc1, const orbx_keypoint *kps1, int n1, const uint8_t *valid1,
+                                     const int32_t *fv1_node, const int32_t *fv1_off, const int32_t *fv1_idx, int fv1_n,
+                                     const uint8_t *desc2, const orbx_keypoint *kps2, int n2, const uint8_t *valid2,
+                                     const int32_t *fv2_node, const int32_t *fv2_off, const int32_t *fv2_idx, int fv2_n,
+                                     float nnratio, int check_orientation, int32_t *matches12, int *nmatches)
+{
+    if (!m) return mfail(ORBX_E_INVALID, "NULL handle");
+    if (n1 < 0 || n2 < 0 || fv1_n < 0 || fv2_n < 0 || !matches12 || !nmatches) return mfail(ORBX_E_INVALID, "bad argument");
+    *nmatches = 0;
+    for (int i = 0; i < n1; i++) matches12[i] = -1;                             // :534
+    if (n1 == 0 || n2 == 0 || fv1_n == 0 || fv2_n == 0) return ORBX_OK;
+    if (!fv2_node || !fv2_off || !fv2_idx || !valid1 || !valid2) return mfail(ORBX_E_INVALID, "NULL buffer");
+    std::vector<int32_t> off2((size_t)fv2_n + 1, 0), idx2;
+    idx2.reserve((size_t)std::max(fv2_off[fv2_n], 0));
+    for (int b = 0; b < fv2_n; b++) {
+        for (int c = fv2_off[b]; c < fv2_off[b + 1]; c++) {
+            const int i2 = fv2_idx[c];
+            if (i2 < 0 || i2 >= n2) return mfail(ORBX_E_INVALID, "feature index %d outside [0,%d)", i2, n2);
+            if (valid2[i2]) idx2.push_back(i2);
+        }
+        off2[(size_t)b + 1] = (int32_t)idx2.size();
+    }
+    if (idx2.empty()) return ORBX_OK;
+    std::vector<int32_t> match2((size_t)n2, -1);
+    int rc = search_by_bow_impl(m, desc1, kps1, n1, valid1, fv1_node, fv1_off, fv1_idx, fv1_n, desc2, kps2, n2,
+                                fv2_node, off2.data(), idx2.data(), fv2_n, nnratio, ORBM_TH_LOW - 1, check_orientation, match2.data(), nmatches);
+    if (rc != ORBX_OK) return rc;
+    for (int i2 = 0; i2 < n2; i2++)
+        if (match2[i2] >= 0) matches12[match2[i2]] = i2;
     return ORBX_OK;
 }
 

@@ -83,31 +83,6 @@ __global__ __launch_bounds__(G_THREADS) void k_grid_build(OrbmGrid g, const orbx
     }
 }
 
-// cell range of a window, src/Frame.cc:332-346.  Returns false when the window misses the grid.
-__device__ __forceinline__ bool window_cells(const OrbmGrid &g, float x, float y, float r,
-                                             int &cx0, int &cx1, int &cy0, int &cy1)
-{
-    cx0 = max(0, (int)floorf(__fmul_rn(__fsub_rn(__fsub_rn(x, g.min_x), r), g.inv_w)));
-    if (cx0 >= ORBM_GRID_COLS) return false;
-    cx1 = min(ORBM_GRID_COLS - 1, (int)ceilf(__fmul_rn(__fadd_rn(__fsub_rn(x, g.min_x), r), g.inv_w)));
-    if (cx1 < 0) return false;
-    cy0 = max(0, (int)floorf(__fmul_rn(__fsub_rn(__fsub_rn(y, g.min_y), r), g.inv_h)));
-    if (cy0 >= ORBM_GRID_ROWS) return false;
-    cy1 = min(ORBM_GRID_ROWS - 1, (int)ceilf(__fmul_rn(__fadd_rn(__fsub_rn(y, g.min_y), r), g.inv_h)));
-    if (cy1 < 0) return false;
-    return true;
-}
-
-__device__ __forceinline__ bool in_window(const OrbmGrid &g, int i, float x, float y, float r, int minl, int maxl)
-{
-    if ((minl > 0) || (maxl >= 0)) {                       // bCheckLevels :348
-        const int oct = g.koct[i];
-        if (oct < minl) return false;
-        if (maxl >= 0 && oct > maxl) return false;
-    }
-    return fabsf(__fsub_rn(g.kx[i], x)) < r && fabsf(__fsub_rn(g.ky[i], y)) < r;   // :368-372
-}
-
 // one wave per window; MODE 0 = count, 1 = write the list at off[q] in the reference's order
 template <int MODE>
 __global__ __launch_bounds__(M_THREADS) void k_area_list(OrbmGrid g, const float *__restrict__ qx, const float *__restrict__ qy,
@@ -204,16 +179,16 @@ __global__ __launch_bounds__(M_THREADS) void k_search_area(OrbmGrid g, const uin
 // -------------------------------------------------------------------------------------------------
 // C ABI
 // -------------------------------------------------------------------------------------------------
-static int ensure_grid(orbm_matcher *m)
+static int ensure_grid(orbm_matcher *m, OrbmGrid &g)
 {
-    if (m->grid.cell_start) return ORBX_OK;
+    if (g.cell_start) return ORBX_OK;
     const size_t n = (size_t)m->max_t;
-    MHIPCHK(hipMalloc((void **)&m->grid.kx, n * 4));
-    MHIPCHK(hipMalloc((void **)&m->grid.ky, n * 4));
-    MHIPCHK(hipMalloc((void **)&m->grid.koct, n * 4));
-    MHIPCHK(hipMalloc((void **)&m->grid.items, n * 4));
-    MHIPCHK(hipMalloc((void **)&m->grid.cell_of, n * 4));
-    MHIPCHK(hipMalloc((void **)&m->grid.cell_start, (ORBM_GRID_CELLS + 1) * 4));
+    MHIPCHK(hipMalloc((void **)&g.kx, n * 4));
+    MHIPCHK(hipMalloc((void **)&g.ky, n * 4));
+    MHIPCHK(hipMalloc((void **)&g.koct, n * 4));
+    MHIPCHK(hipMalloc((void **)&g.items, n * 4));
+    MHIPCHK(hipMalloc((void **)&g.cell_of, n * 4));
+    MHIPCHK(hipMalloc((void **)&g.cell_start, (ORBM_GRID_CELLS + 1) * 4));
     return ORBX_OK;
 }
 
@@ -283,32 +258,65 @@ extern "C" int orbm_image_bounds(int width, int height, float fx, float fy, floa
     return ORBX_OK;
 }
 
-extern "C" int orbm_grid_build(orbm_matcher *m, const orbx_keypoint *kps_un, int n,
-                               float min_x, float max_x, float min_y, float max_y)
+// Builds a grid slot.  The keypoints are staged in the pinned arena of the current call (the caller has run orbm_arena_begin) and
+// go to the handle's d_out (a temporary block when that is too small); the kernel is queued on the handle's stream.
+int orbm_grid_build_into(orbm_matcher *m, OrbmGrid &g, const orbx_keypoint *kps_un, int n, float assign_min_x, float assign_min_y,
+                         float inv_w, float inv_h, float query_min_x, float query_min_y)
 {
-    if (!m) return mfail(ORBX_E_INVALID, "NULL handle");
-    if (n < 0 || n > m->max_t) return mfail(ORBX_E_CAPACITY, "n=%d keypoints, matcher sized for %d", n, m->max_t);
-    if (n > 0 && !kps_un) return mfail(ORBX_E_INVALID, "NULL keypoints");
-    if (!(max_x > min_x) || !(max_y > min_y)) return mfail(ORBX_E_INVALID, "empty image bounds");
-    MHIPCHK(hipSetDevice(m->device));
-    { int rc_ = orbm_arena_begin(m); if (rc_ != ORBX_OK) return rc_; }
-    int rc = ensure_grid(m);
+    int rc = ensure_grid(m, g);
     if (rc != ORBX_OK) return rc;
-    m->grid.min_x = min_x; m->grid.min_y = min_y;
-    m->grid.inv_w = (float)ORBM_GRID_COLS / (max_x - min_x);     // src/Frame.cc:212
-    m->grid.inv_h = (float)ORBM_GRID_ROWS / (max_y - min_y);     // :213
-    m->grid.n = n;
+    g.min_x = assign_min_x; g.min_y = assign_min_y; g.inv_w = inv_w; g.inv_h = inv_h; g.qmin_x = query_min_x; g.qmin_y = query_min_y;
+    g.n = n;
     hipStream_t s = m->stream;
-    orbx_keypoint *d_kps = reinterpret_cast<orbx_keypoint *>(m->d_out);   // staging: 3*max_q ints >= 7*n? checked below
+    orbx_keypoint *d_kps = reinterpret_cast<orbx_keypoint *>(m->d_out);
     const size_t need = (size_t)n * sizeof(orbx_keypoint);
     const size_t have = std::max<size_t>((size_t)3 * m->max_q, (size_t)m->max_pairs) * 4;
     void *tmp = nullptr;
     if (need > have) { MHIPCHK(hipMalloc(&tmp, need)); d_kps = reinterpret_cast<orbx_keypoint *>(tmp); }
     if (n > 0) { int rc_ = orbm_h2d(m, d_kps, kps_un, need, s); if (rc_ != ORBX_OK) return rc_; }
-    hipLaunchKernelGGL(k_grid_build, dim3(1), dim3(G_THREADS), 0, s, m->grid, d_kps);
+    hipLaunchKernelGGL(k_grid_build, dim3(1), dim3(G_THREADS), 0, s, g, d_kps);
     MHIPCHK(hipGetLastError());
-    { int rc_ = orbm_sync(m, s); if (rc_ != ORBX_OK) return rc_; }
-    if (tmp) (void)hipFree(tmp);
+    if (tmp) { MHIPCHK(hipStreamSynchronize(s)); (void)hipFree(tmp); }
+    return ORBX_OK;
+}
+
+extern "C" int orbm_grid_build(orbm_matcher *m, const orbx_keypoint *kps_un, int n,
+                               float min_x, float max_x, float min_y, float max_y)
+{
+    if (!m) return mfail(ORBX_E_INVALID, "NULL handle");
+    if (n < 0) return mfail(ORBX_E_INVALID, "n=%d keypoints", n);
+    if (n > 0 && !kps_un) return mfail(ORBX_E_INVALID, "NULL keypoints");
+    if (!(max_x > min_x) || !(max_y > min_y)) return mfail(ORBX_E_INVALID, "empty image bounds");
+    MHIPCHK(hipSetDevice(m->device));
+    m->grid_ok = false;
+    { int rc_ = orbm_grow(m, 0, n, 0); if (rc_ != ORBX_OK) return rc_; }
+    { int rc_ = orbm_arena_begin(m); if (rc_ != ORBX_OK) return rc_; }
+    int rc = orbm_grid_build_into(m, m->grid, kps_un, n, min_x, min_y, (float)ORBM_GRID_COLS / (max_x - min_x),     // src/Frame.cc:212
+                                  (float)ORBM_GRID_ROWS / (max_y - min_y), min_x, min_y);                        // :213
+    if (rc != ORBX_OK) return rc;
+    { int rc_ = orbm_sync(m, m->stream); if (rc_ != ORBX_OK) return rc_; }
+    m->grid_ok = true;
+    return ORBX_OK;
+}
+
+// A key frame's grid.  KeyFrame copies mGrid from the Frame it was made of (src/KeyFrame.cc:48-54), so the cells were filled by
+// Frame::PosInGrid with Frame's float mnMinX / mnMinY and mfGridElementWidthInv / HeightInv (src/Frame.cc:382-392: assign_*, inv_*),
+// while KeyFrame::GetFeaturesInArea (src/KeyFrame.cc:569-606) subtracts the key frame's own mnMinX / mnMinY, which are ints
+// (include/KeyFrame.h:190-193: query_*).  With the shipped calibration (k1 == 0) the two origins coincide.
+extern "C" int orbm_grid_build_kf(orbm_matcher *m, const orbx_keypoint *kps_un, int n, float assign_min_x, float assign_min_y,
+                                  float inv_w, float inv_h, float query_min_x, float query_min_y)
+{
+    if (!m) return mfail(ORBX_E_INVALID, "NULL handle");
+    if (n < 0) return mfail(ORBX_E_INVALID, "n=%d keypoints", n);
+    if (n > 0 && !kps_un) return mfail(ORBX_E_INVALID, "NULL keypoints");
+    if (!(inv_w > 0.f) || !(inv_h > 0.f)) return mfail(ORBX_E_INVALID, "grid cell sizes must be positive");
+    MHIPCHK(hipSetDevice(m->device));
+    m->grid_ok = false;
+    { int rc_ = orbm_grow(m, 0, n, 0); if (rc_ != ORBX_OK) return rc_; }
+    { int rc_ = orbm_arena_begin(m); if (rc_ != ORBX_OK) return rc_; }
+    int rc = orbm_grid_build_into(m, m->grid, kps_un, n, assign_min_x, assign_min_y, inv_w, inv_h, query_min_x, query_min_y);
+    if (rc != ORBX_OK) return rc;
+    { int rc_ = orbm_sync(m, m->stream); if (rc_ != ORBX_OK) return rc_; }
     m->grid_ok = true;
     return ORBX_OK;
 }
@@ -355,7 +363,7 @@ extern "C" int orbm_features_in_area(orbm_matcher *m, const float *x, const floa
     if (total > cap_idx) return mfail(ORBX_E_CAPACITY, "%d candidates, caller capacity %d", total, cap_idx);
     if (total == 0) return 0;
     if (!cand_idx) return mfail(ORBX_E_INVALID, "cand_idx is NULL");
-    if (total > m->max_pairs) return mfail(ORBX_E_CAPACITY, "%d candidates, matcher sized for %d pairs", total, m->max_pairs);
+    if (total > m->max_pairs) { int rc_ = orbm_grow(m, 0, 0, total); if (rc_ != ORBX_OK) return rc_; }
     { int rc_ = orbm_h2d(m, d_off, cand_off, (size_t)nq * 4, s); if (rc_ != ORBX_OK) return rc_; }
     hipLaunchKernelGGL(k_area_list<1>, grid, dim3(M_THREADS), 0, s, m->grid, m->d_qf, m->d_qf + Q, m->d_qf + 2 * Q, m->d_qi, m->d_qi + Q,
                        nq, (int32_t *)nullptr, d_off, m->d_idx);
@@ -390,8 +398,9 @@ extern "C" int orbm_search_area_best2(orbm_matcher *m, const uint8_t *qdesc, con
 {
     if (!m) return mfail(ORBX_E_INVALID, "NULL handle");
     if (!m->grid_ok) return mfail(ORBX_E_INVALID, "orbm_grid_build has not been called");
-    if (nq < 0 || nq > m->max_q) return mfail(ORBX_E_CAPACITY, "nq=%d, matcher sized for %d", nq, m->max_q);
+    if (nq < 0) return mfail(ORBX_E_INVALID, "nq=%d", nq);
     if (nq == 0) return ORBX_OK;
+    { int rc_ = orbm_grow(m, nq, 0, 0); if (rc_ != ORBX_OK) return rc_; }
     if (!qdesc || !x || !y || !r || !min_level || !max_level || !best_idx || !best_d || !second_d || (m->grid.n > 0 && !train_desc))
         return mfail(ORBX_E_INVALID, "NULL buffer");
     MHIPCHK(hipSetDevice(m->device));
@@ -443,7 +452,7 @@ extern "C" int orbm_search_area_best2(orbm_matcher *m, const uint8_t *qdesc, con
 // back, offsets go up, lists and distances come back -- two synchronisations.  (One pass into fixed per-window slots was
 // measured: the fullest windows need > 128 slots, and copying nq x slots back costs more than the second round trip.)
 // Falls back to the two public calls when the arena has no room yet (first call).
-static int area_pairs(orbm_matcher *m, const float *x, const float *y, const float *r, const int32_t *mn, const int32_t *mx, int nq,
+int orbm_area_pairs(orbm_matcher *m, const float *x, const float *y, const float *r, const int32_t *mn, const int32_t *mx, int nq,
                       const uint8_t *qdesc, const uint8_t *train_desc, int n_train,
                       std::vector<int32_t> &off, std::vector<int32_t> &idx, std::vector<int32_t> &dist)
 {
@@ -484,7 +493,7 @@ static int area_pairs(orbm_matcher *m, const float *x, const float *y, const flo
     const int total = off[nq];
     idx.assign((size_t)std::max(total, 1), 0); dist.assign((size_t)std::max(total, 1), 0);
     if (total == 0) return 0;
-    if (total > m->max_pairs) return mfail(ORBX_E_CAPACITY, "%d candidates, matcher sized for %d pairs", total, m->max_pairs);
+    if (total > m->max_pairs) { int rc_ = orbm_grow(m, 0, 0, total); if (rc_ != ORBX_OK) return rc_; }     // d_idx / d_out hold nothing yet
     uint8_t *h_off = m->arena + ((uint8_t *)soff - m->d_arena);
     memcpy(h_off, off.data(), ((size_t)nq + 1) * 4);
     MHIPCHK(hipMemcpyAsync(soff, h_off, ((size_t)nq + 1) * 4, hipMemcpyHostToDevice, s));
@@ -524,7 +533,7 @@ extern "C" int orbm_search_for_initialization(orbm_matcher *m, const orbx_keypoi
         if (kps1[i].octave <= 0) qi.push_back(i);
     const int nq = (int)qi.size();
     if (nq == 0) return ORBX_OK;
-    if (nq > m->max_q) return mfail(ORBX_E_CAPACITY, "%d level-0 keypoints, matcher sized for %d queries", nq, m->max_q);
+    { int rc_ = orbm_grow(m, nq, 0, 0); if (rc_ != ORBX_OK) return rc_; }
     std::vector<float> x(nq), y(nq), r(nq, (float)window_size);
     std::vector<int32_t> lv(nq), off, idx, dist;
     std::vector<uint8_t> qd((size_t)nq * 32);
@@ -533,7 +542,7 @@ extern "C" int orbm_search_for_initialization(orbm_matcher *m, const orbx_keypoi
         x[k] = prev_matched[2 * i]; y[k] = prev_matched[2 * i + 1]; lv[k] = kps1[i].octave;
         memcpy(&qd[(size_t)k * 32], desc1 + (size_t)i * 32, 32);
     }
-    const int total = area_pairs(m, x.data(), y.data(), r.data(), lv.data(), lv.data(), nq, qd.data(), desc2, n2, off, idx, dist);
+    const int total = orbm_area_pairs(m, x.data(), y.data(), r.data(), lv.data(), lv.data(), nq, qd.data(), desc2, n2, off, idx, dist);
     if (total < 0) return total;
     // the sequential scan (:418-487)
     std::vector<int> matched_dist((size_t)n2, INT_MAX), matches21((size_t)n2, -1);
@@ -583,10 +592,20 @@ extern "C" int orbm_search_for_initialization(orbm_matcher *m, const orbx_keypoi
 }
 
 // ---- ORBmatcher::SearchByProjection(Frame&, const Frame&, th, bMono) (src/ORBmatcher.cc:1328-1470) ----
-static inline float gemm_row(const float *T, int row, const float *x)      // (R x + t)[row] as OpenCV's float GEMM: double sum, one rounding
+// (R x + t)[row] as OpenCV 3.1.0 evaluates `R*x + t` on a 3x3 and a 3x1 float matrix: one cv::gemm(R, x, 1, t, 1, dst, 0) call, whose
+// small-matrix path (modules/core/src/matmul.cpp: flags == 0, 2 <= len <= 4) sums the three products in float, left to right, and
+// finishes with (float)(t0*alpha + c*beta) in double.  `-R.t()*t` materialises the transpose and takes the same path with alpha = -1.
+static inline float gemm_row(const float *T, int row, const float *x)
 {
-    const double s = (double)T[4 * row] * x[0] + (double)T[4 * row + 1] * x[1] + (double)T[4 * row + 2] * x[2];
-    return (float)(s + (double)T[4 * row + 3]);
+    const float t0 = T[4 * row] * x[0] + T[4 * row + 1] * x[1] + T[4 * row + 2] * x[2];
+    return (float)((double)t0 * 1.0 + (double)T[4 * row + 3] * 1.0);
+}
+static inline void camera_center(const float *T, float Ow[3])
+{
+    for (int k = 0; k < 3; k++) {
+        const float t0 = T[k] * T[3] + T[4 + k] * T[7] + T[8 + k] * T[11];
+        Ow[k] = (float)((double)t0 * -1.0 + 0.0 * 0.0);       // no C operand: c = zerof, beta = 0 (a zero sum comes out as +0)
+    }
 }
 extern "C" int orbm_search_by_projection_last(orbm_matcher *m, int n_last, const uint8_t *has_point, const float *xw, const uint8_t *mp_desc,
                                               const int32_t *mp_obs, const orbx_keypoint *kps_last, const float *Tcw, const float *Tlw,
@@ -604,8 +623,7 @@ extern "C" int orbm_search_by_projection_last(orbm_matcher *m, int n_last, const
     if (n_last == 0 || n_cur == 0) return ORBX_OK;
     if (!m->grid_ok || m->grid.n != n_cur) return mfail(ORBX_E_INVALID, "orbm_grid_build(current frame) has not been called");
     float twc[3];                                   // :1342-1350
-    for (int k = 0; k < 3; k++)
-        twc[k] = (float)((double)(-Tcw[k]) * Tcw[3] + (double)(-Tcw[4 + k]) * Tcw[7] + (double)(-Tcw[8 + k]) * Tcw[11]);
+    camera_center(Tcw, twc);
     const float tlc2 = gemm_row(Tlw, 2, twc);
     const bool forward = tlc2 > mb && !mono, backward = -tlc2 > mb && !mono;
     // projections (:1352-1394): one window per last-frame feature that survives the checks
@@ -633,11 +651,11 @@ extern "C" int orbm_search_by_projection_last(orbm_matcher *m, int n_last, const
     }
     const int nq = (int)qs.size();
     if (nq == 0) return ORBX_OK;
-    if (nq > m->max_q) return mfail(ORBX_E_CAPACITY, "%d projected points, matcher sized for %d queries", nq, m->max_q);
+    { int rc_ = orbm_grow(m, nq, 0, 0); if (rc_ != ORBX_OK) return rc_; }
     std::vector<int32_t> off, idx, dist;
     std::vector<uint8_t> qd((size_t)nq * 32);
     for (int k = 0; k < nq; k++) memcpy(&qd[(size_t)k * 32], mp_desc + (size_t)qs[k].i * 32, 32);
-    const int total = area_pairs(m, x.data(), y.data(), r.data(), mn.data(), mx.data(), nq, qd.data(), desc_cur, n_cur, off, idx, dist);
+    const int total = orbm_area_pairs(m, x.data(), y.data(), r.data(), mn.data(), mx.data(), nq, qd.data(), desc_cur, n_cur, off, idx, dist);
     if (total < 0) return total;
     // the sequential scan (:1396-1444)
     std::vector<std::pair<int, int>> rot;
@@ -691,9 +709,8 @@ extern "C" int orbm_project_points(const float *Tcw, float fx, float fy, float c
                                    const float *xw, int n, float *u, float *v, float *invzc, float *dist3d, uint8_t *in_image)
 {
     if (!Tcw || !bounds || n < 0 || (n > 0 && (!xw || !u || !v || !in_image))) return mfail(ORBX_E_INVALID, "bad argument");
-    float Ow[3];                                    // Ow = -Rcw^T tcw (:1478), cv::Mat algebra as OpenCV's float GEMM
-    for (int k = 0; k < 3; k++)
-        Ow[k] = (float)((double)(-Tcw[k]) * Tcw[3] + (double)(-Tcw[4 + k]) * Tcw[7] + (double)(-Tcw[8 + k]) * Tcw[11]);
+    float Ow[3];                                    // Ow = -Rcw^T tcw (:1478)
+    camera_center(Tcw, Ow);
     for (int i = 0; i < n; i++) {
         const float *X = xw + 3 * (size_t)i;
         const float xc = gemm_row(Tcw, 0, X), yc = gemm_row(Tcw, 1, X), zc = gemm_row(Tcw, 2, X);   // :1498
@@ -746,11 +763,11 @@ extern "C" int orbm_search_by_projection_kf(orbm_matcher *m, int n_mp, const uin
     }
     const int nq = (int)qi.size();
     if (nq == 0) return ORBX_OK;
-    if (nq > m->max_q) return mfail(ORBX_E_CAPACITY, "%d projected points, matcher sized for %d queries", nq, m->max_q);
+    { int rc_ = orbm_grow(m, nq, 0, 0); if (rc_ != ORBX_OK) return rc_; }
     std::vector<int32_t> off, idx, dist;
     std::vector<uint8_t> qd((size_t)nq * 32);
     for (int k = 0; k < nq; k++) memcpy(&qd[(size_t)k * 32], mp_desc + (size_t)qi[k] * 32, 32);
-    const int total = area_pairs(m, x.data(), y.data(), r.data(), mn.data(), mx.data(), nq, qd.data(), desc_cur, n_cur, off, idx, dist);
+    const int total = orbm_area_pairs(m, x.data(), y.data(), r.data(), mn.data(), mx.data(), nq, qd.data(), desc_cur, n_cur, off, idx, dist);
     if (total < 0) return total;
     // the sequential scan (:1538-1575): an assignment blocks the slot for every later MapPoint
     std::vector<std::pair<int, int>> rot;
@@ -822,11 +839,11 @@ extern "C" int orbm_search_by_projection_map(orbm_matcher *m, int n_mp, const ui
     }
     const int nq = (int)qi.size();
     if (nq == 0) return ORBX_OK;
-    if (nq > m->max_q) return mfail(ORBX_E_CAPACITY, "%d MapPoints in view, matcher sized for %d queries", nq, m->max_q);
+    { int rc_ = orbm_grow(m, nq, 0, 0); if (rc_ != ORBX_OK) return rc_; }
     std::vector<int32_t> off, idx, dist;
     std::vector<uint8_t> qd((size_t)nq * 32);
     for (int k = 0; k < nq; k++) memcpy(&qd[(size_t)k * 32], mp_desc + (size_t)qi[k] * 32, 32);
-    const int total = area_pairs(m, x.data(), y.data(), r.data(), mn.data(), mx.data(), nq, qd.data(), desc_cur, n_cur, off, idx, dist);
+    const int total = orbm_area_pairs(m, x.data(), y.data(), r.data(), mn.data(), mx.data(), nq, qd.data(), desc_cur, n_cur, off, idx, dist);
     if (total < 0) return total;
     int nm = 0;
     for (int k = 0; k < nq; k++) {                  // :73-122

@@ -1434,10 +1434,24 @@ int oro_search_for_initialization(const oro_keypoint *kps1, const uint8_t *desc1
 }
 
 /* ---- ORBmatcher::SearchByProjection(Frame&, const Frame&, th, bMono), src/ORBmatcher.cc:1328-1470 ---- */
-static float oro_gemm_row(const float *T, int row, const float *x)      /* (R x + t)[row]: double accumulation, one rounding */
+/* OpenCV 3.1.0: cv::Mat algebra on 3x3 * 3x1 float matrices.  `R*x + t` is one cv::gemm(R, x, 1, t, 1, dst, 0) call (MatOp_GEMM), and
+ * cv::gemm (modules/core/src/matmul.cpp) has a small-matrix path for `flags == 0 && 2 <= len && len <= 4 && (len == d_size.width ||
+ * len == d_size.height)`: for CV_32F the three products are summed IN FLOAT, left to right, `float t0 = a[0]*b[0] + a[1]*b[b_step] +
+ * a[2]*b[b_step*2]`, and the element is `(float)(t0*alpha + c[0]*beta)` with alpha, beta doubles.  Unary minus on a transpose
+ * expression (`-Rcw.t()*tcw`) materialises the transpose (MatOp::subtract(Scalar, MatExpr) assigns the expression) and scales by
+ * alpha = -1, so that product runs through the same path with flags == 0.  (Rounds 1-2 restated these products with double
+ * accumulation -- GEMMSingleMul's arithmetic, which only non-small or transposed-flag products reach.) */
+float oro_gemm_row(const float *T, int row, const float *x)      /* (R x + t)[row] of a row-major 4x4 [R|t] */
 {
-    const double s = (double)T[4 * row] * x[0] + (double)T[4 * row + 1] * x[1] + (double)T[4 * row + 2] * x[2];
-    return (float)(s + (double)T[4 * row + 3]);
+    const float t0 = T[4 * row] * x[0] + T[4 * row + 1] * x[1] + T[4 * row + 2] * x[2];
+    return (float)((double)t0 * 1.0 + (double)T[4 * row + 3] * 1.0);
+}
+void oro_camera_center(const float *T, float Ow[3])                /* -R^T t: KeyFrame::SetPose's Ow (src/KeyFrame.cc), :303, :990, :1342, :1478 */
+{
+    for (int k = 0; k < 3; k++) {
+        const float t0 = T[k] * T[3] + T[4 + k] * T[7] + T[8 + k] * T[11];
+        Ow[k] = (float)((double)t0 * -1.0 + 0.0 * 0.0);       /* no C operand: c = zerof, beta = 0 (a zero sum comes out as +0) */
+    }
 }
 int oro_search_by_projection_last(int n_last, const uint8_t *has_point, const float *xw, const uint8_t *mp_desc, const int32_t *mp_obs,
                                   const oro_keypoint *kps_last, const float *Tcw, const float *Tlw,
@@ -1453,10 +1467,7 @@ int oro_search_by_projection_last(int n_last, const uint8_t *has_point, const fl
     for (int i = 0; i < n_cur; i++) cur_match[i] = -1;
     /* twc = -Rcw^T tcw (:1342); tlc = Rlw twc + tlw (:1347): only the z component is used */
     float twc[3], tlc2;
-    for (int k = 0; k < 3; k++) {
-        const double s = (double)(-Tcw[k]) * Tcw[3] + (double)(-Tcw[4 + k]) * Tcw[7] + (double)(-Tcw[8 + k]) * Tcw[11];
-        twc[k] = (float)s;
-    }
+    oro_camera_center(Tcw, twc);
     tlc2 = oro_gemm_row(Tlw, 2, twc);
     const int forward = tlc2 > mb && !mono, backward = -tlc2 > mb && !mono;     /* :1349-1350 */
     for (int i = 0; i < n_last; i++) {
@@ -1563,7 +1574,7 @@ int oro_search_by_projection_map(int n_mp, const uint8_t *in_view, const float *
  * max_dist_inv = GetMin/MaxDistanceInvariance(); mf_max_distance = the MapPoint's mfMaxDistance (PredictScale, src/MapPoint.cc:402-417);
  * mp_desc = GetDescriptor(); kf_angle[i] = pKF->mvKeysUn[i].angle.  Current frame: Tcw row-major 4x4, grid g of kps_cur (mvKeysUn),
  * log_scale_factor = mfLogScaleFactor, cur_has_point[i2] = (mvpMapPoints[i2] != NULL) in/out, cur_match[i2] out = i or -1.
- * cv::Mat algebra as OpenCV's float GEMM (double accumulation, one rounding); cv::norm of a float vector accumulates in double;
+ * cv::Mat algebra as cv::gemm's small-matrix path (oro_gemm_row: float accumulation, then alpha / beta in double); cv::norm of a float vector accumulates in double;
  * log() of a float resolves to logf in the reference's translation unit (decision). */
 int oro_predict_scale(float mf_max_distance, float current_dist, float log_scale_factor, int n_levels)
 {
@@ -1585,10 +1596,7 @@ int oro_search_by_projection_kf(int n_kf, const uint8_t *usable, const float *xw
     for (int i = 0; i < 30; i++) hist[i] = 0;
     for (int i = 0; i < n_cur; i++) cur_match[i] = -1;
     float Ow[3];                                                        /* Ow = -Rcw^T tcw, :1478 */
-    for (int k = 0; k < 3; k++) {
-        const double s = (double)(-Tcw[k]) * Tcw[3] + (double)(-Tcw[4 + k]) * Tcw[7] + (double)(-Tcw[8 + k]) * Tcw[11];
-        Ow[k] = (float)s;
-    }
+    oro_camera_center(Tcw, Ow);
     for (int i = 0; i < n_kf; i++) {
         if (!usable[i]) continue;                                      /* :1492-1494 */
         const float *X = xw + 3 * (size_t)i;

@@ -155,7 +155,7 @@ int oro_search_for_initialization(const oro_keypoint *kps1, const uint8_t *desc1
  * mp_desc = GetDescriptor(), mp_obs = Observations(), kps_last = mvKeys/mvKeysUn (octave, angle).  Current frame: poses as
  * row-major 4x4 float, grid g of kps_cur (mvKeysUn), u_right = mvuRight or NULL, cur_obs[i2] = -1 for a NULL mvpMapPoints
  * entry else that point's Observations() (in/out), cur_match[i2] = last-frame feature assigned by this call or -1 (out).
- * cv::Mat algebra (Rcw * x + tcw) as OpenCV's float GEMM does it: double accumulation, one rounding to float. */
+ * cv::Mat algebra (Rcw * x + tcw) as cv::gemm's small-matrix path does it (oro_gemm_row in orb_oracle.c). */
 int oro_search_by_projection_last(int n_last, const uint8_t *has_point, const float *xw, const uint8_t *mp_desc, const int32_t *mp_obs,
                                   const oro_keypoint *kps_last, const float *Tcw, const float *Tlw,
                                   float fx, float fy, float cx, float cy, float mb, float mbf, const float bounds[4],
@@ -179,6 +179,48 @@ int oro_search_by_projection_kf(int n_kf, const uint8_t *usable, const float *xw
                                 float fx, float fy, float cx, float cy, const float bounds[4], const float *scale_factors, int nlevels,
                                 float log_scale_factor, const oro_grid *g, const oro_keypoint *kps_cur, const uint8_t *desc_cur, int n_cur,
                                 float th, int orb_dist, int check_orientation, uint8_t *cur_has_point, int32_t *cur_match);
+/* cv::Mat 3x3 * 3x1 algebra of OpenCV 3.1.0 (cv::gemm's small-matrix path; see orb_oracle.c): (R x + t)[row] of a row-major 4x4 [R|t],
+ * and the camera centre -R^T t. */
+float oro_gemm_row(const float *T, int row, const float *x);
+void oro_camera_center(const float *T, float Ow[3]);
+
+/* ---- the LocalMapping / LoopClosing matchers (orb_oracle_kf.c; arguments documented there) ---- */
+void oro_grid_build_kf(oro_grid *g, const oro_keypoint *kps_un, int n, float assign_min_x, float assign_min_y,
+                       float inv_w, float inv_h, float query_min_x, float query_min_y, int *items);
+void oro_sim3_decompose(const float *Scw, float T[16], float Ow[3]);                        /* src/ORBmatcher.cc:299-303 */
+int oro_search_by_projection_sim3(int n_mp, const uint8_t *usable, const float *xw, const float *normal, const float *min_dist_inv,
+                                  const float *max_dist_inv, const float *mf_max_distance, const uint8_t *mp_desc, const float *Scw,
+                                  float fx, float fy, float cx, float cy, const float bounds[4], const float *scale_factors, int nlevels,
+                                  float log_scale_factor, const oro_grid *g, const oro_keypoint *kps_kf, const uint8_t *desc_kf, int n_kf,
+                                  int th, uint8_t *kf_matched, int32_t *kf_match);          /* :290-403 */
+int oro_search_by_bow_kf(const uint8_t *desc1, const float *angle1, int n1, const uint8_t *valid1,
+                         const int32_t *node1, const int32_t *off1, const int32_t *idx1v, int nn1,
+                         const uint8_t *desc2, const float *angle2, int n2, const uint8_t *valid2,
+                         const int32_t *node2, const int32_t *off2, const int32_t *idx2v, int nn2,
+                         float nnratio, int check_orientation, int32_t *matches12);         /* :522-655 */
+int oro_search_for_triangulation(const oro_keypoint *kps1, const uint8_t *desc1, int n1, const uint8_t *has_mp1, const float *u_right1,
+                                 const int32_t *node1, const int32_t *off1, const int32_t *idx1v, int nn1,
+                                 const oro_keypoint *kps2, const uint8_t *desc2, int n2, const uint8_t *has_mp2, const float *u_right2,
+                                 const int32_t *node2, const int32_t *off2, const int32_t *idx2v, int nn2,
+                                 const float *Cw, const float *T2w, float fx2, float fy2, float cx2, float cy2, const float *F12,
+                                 const float *scale_factors2, const float *level_sigma2_2, int only_stereo, int check_orientation,
+                                 int32_t *matches12);                                       /* :657-823 */
+int oro_fuse(int n_mp, const uint8_t *usable, const float *xw, const float *normal, const float *min_dist_inv, const float *max_dist_inv,
+             const float *mf_max_distance, const uint8_t *mp_desc, const float *Tcw, const float *Ow, float fx, float fy, float cx, float cy,
+             float bf, const float bounds[4], const float *scale_factors, const float *inv_level_sigma2, int nlevels, float log_scale_factor,
+             const oro_grid *g, const oro_keypoint *kps_kf, const float *u_right_kf, const uint8_t *desc_kf, int n_kf, float th,
+             int32_t *best_idx);                                                            /* :825-975 */
+int oro_fuse_sim3(int n_mp, const uint8_t *usable, const float *xw, const float *normal, const float *min_dist_inv, const float *max_dist_inv,
+                  const float *mf_max_distance, const uint8_t *mp_desc, const float *Scw, float fx, float fy, float cx, float cy,
+                  const float bounds[4], const float *scale_factors, int nlevels, float log_scale_factor, const oro_grid *g,
+                  const oro_keypoint *kps_kf, const uint8_t *desc_kf, int n_kf, float th, int32_t *best_idx);   /* :977-1100 */
+int oro_search_by_sim3(int n1, const uint8_t *usable1, const float *xw1, const float *min_dist1, const float *max_dist1,
+                       const float *mf_max1, const uint8_t *mp_desc1, const float *T1w, const float bounds1[4], const float *scale_factors1,
+                       int nlevels1, float log_scale_factor1, const oro_grid *g1, const oro_keypoint *kps1, const uint8_t *desc1,
+                       int n2, const uint8_t *usable2, const float *xw2, const float *min_dist2, const float *max_dist2,
+                       const float *mf_max2, const uint8_t *mp_desc2, const float *T2w, const float bounds2[4], const float *scale_factors2,
+                       int nlevels2, float log_scale_factor2, const oro_grid *g2, const oro_keypoint *kps2, const uint8_t *desc2,
+                       float fx, float fy, float cx, float cy, float s12, const float *R12, const float *t12, float th, int32_t *match12);   /* :1102-1326 */
 /* AssignFeaturesToGrid + PosInGrid; items must hold n ints */
 void oro_grid_build(oro_grid *g, const oro_keypoint *kps_un, int n, float min_x, float max_x, float min_y, float max_y, int *items);
 /* GetFeaturesInArea: returns the count written to out (reference order), -1 if cap is too small */

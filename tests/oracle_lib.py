@@ -108,6 +108,30 @@ def lib(native=False):
                                     C.c_float, C.c_int, vp]
     L.oro_search_by_bow.restype = C.c_int
     L.oro_match_dense.restype = C.c_int
+    f = C.c_float
+    L.oro_gemm_row.argtypes = [vp, C.c_int, vp]
+    L.oro_gemm_row.restype = C.c_float
+    L.oro_camera_center.argtypes = [vp, vp]
+    L.oro_camera_center.restype = None
+    L.oro_grid_build_kf.argtypes = [vp, vp, C.c_int, f, f, f, f, f, f, vp]
+    L.oro_grid_build_kf.restype = None
+    L.oro_sim3_decompose.argtypes = [vp, vp, vp]
+    L.oro_sim3_decompose.restype = None
+    L.oro_search_by_projection_sim3.argtypes = [C.c_int, vp, vp, vp, vp, vp, vp, vp, vp, f, f, f, f, vp, vp, C.c_int, f, vp, vp, vp, C.c_int,
+                                                C.c_int, vp, vp]
+    L.oro_search_by_projection_sim3.restype = C.c_int
+    L.oro_search_by_bow_kf.argtypes = [vp, vp, C.c_int, vp, vp, vp, vp, C.c_int, vp, vp, C.c_int, vp, vp, vp, vp, C.c_int, f, C.c_int, vp]
+    L.oro_search_by_bow_kf.restype = C.c_int
+    L.oro_search_for_triangulation.argtypes = [vp, vp, C.c_int, vp, vp, vp, vp, vp, C.c_int, vp, vp, C.c_int, vp, vp, vp, vp, vp, C.c_int,
+                                               vp, vp, f, f, f, f, vp, vp, vp, C.c_int, C.c_int, vp]
+    L.oro_search_for_triangulation.restype = C.c_int
+    L.oro_fuse.argtypes = [C.c_int, vp, vp, vp, vp, vp, vp, vp, vp, vp, f, f, f, f, f, vp, vp, vp, C.c_int, f, vp, vp, vp, vp, C.c_int, f, vp]
+    L.oro_fuse.restype = C.c_int
+    L.oro_fuse_sim3.argtypes = [C.c_int, vp, vp, vp, vp, vp, vp, vp, vp, f, f, f, f, vp, vp, C.c_int, f, vp, vp, vp, C.c_int, f, vp]
+    L.oro_fuse_sim3.restype = C.c_int
+    side = [C.c_int, vp, vp, vp, vp, vp, vp, vp, vp, vp, C.c_int, f, vp, vp, vp]
+    L.oro_search_by_sim3.argtypes = side + side + [f, f, f, f, f, vp, vp, f, vp]
+    L.oro_search_by_sim3.restype = C.c_int
     if not native:
         _lib = L
     return L
@@ -351,3 +375,114 @@ def image_bounds(w, h, fx, fy, cx, cy, dist5):
     b = np.zeros(4, np.float32)
     lib().oro_image_bounds(w, h, fx, fy, cx, cy, d.ctypes.data, b.ctypes.data)
     return tuple(float(v) for v in b)
+
+
+# ---- the LocalMapping / LoopClosing matchers (oracle/orb_oracle_kf.c) ----
+class KeyFrameGrid(FrameGrid):
+    """KeyFrame's grid: cells assigned with Frame's float origin, queried with the key frame's int origin (orb_oracle_kf.c)."""
+
+    def __init__(self, kps_un, grid):
+        self.L = lib()
+        self.kps = np.ascontiguousarray(kps_un, KP_DTYPE)
+        self.items = np.zeros(max(len(self.kps), 1), np.int32)
+        self.g = OroGrid()
+        self.L.oro_grid_build_kf(C.byref(self.g), _p(self.kps), len(self.kps), *[float(v) for v in grid], _p(self.items))
+
+
+def camera_center(T):
+    T = np.ascontiguousarray(T, np.float32).reshape(16)
+    Ow = np.zeros(3, np.float32)
+    lib().oro_camera_center(_p(T), _p(Ow))
+    return Ow
+
+
+def sim3_decompose(Scw):
+    Scw = np.ascontiguousarray(Scw, np.float32).reshape(16)
+    T, Ow = np.zeros(16, np.float32), np.zeros(3, np.float32)
+    lib().oro_sim3_decompose(_p(Scw), _p(T), _p(Ow))
+    return T.reshape(4, 4), Ow
+
+
+def _f32(a):
+    return np.ascontiguousarray(a, np.float32)
+
+
+def _u8(a):
+    return np.ascontiguousarray(a, np.uint8)
+
+
+def _i32(a):
+    return np.ascontiguousarray(a, np.int32)
+
+
+def search_by_projection_sim3(usable, xw, normal, min_inv, max_inv, mf_max, mp_desc, Scw, K, bounds, scale_factors, log_sf, grid, desc_kf,
+                              kf_matched, th):
+    """SearchByProjection(KeyFrame*, Scw, vpPoints, vpMatched, th) on the oracle -> (kf_match, nmatches); kf_matched uint8 in/out"""
+    usable, xw, normal, mn, mx, mf, mp_desc = _u8(usable), _f32(xw), _f32(normal), _f32(min_inv), _f32(max_inv), _f32(mf_max), _u8(mp_desc)
+    Scw, b, sf, desc_kf = _f32(Scw).reshape(16), _f32(bounds), _f32(scale_factors), _u8(desc_kf)
+    km = np.full(len(grid.kps), -1, np.int32)
+    fx, fy, cx, cy = K
+    n = lib().oro_search_by_projection_sim3(len(usable), _p(usable), _p(xw), _p(normal), _p(mn), _p(mx), _p(mf), _p(mp_desc), _p(Scw), fx, fy, cx, cy,
+                                            _p(b), _p(sf), len(sf), log_sf, C.byref(grid.g), _p(grid.kps), _p(desc_kf), len(grid.kps), int(th),
+                                            _p(kf_matched), _p(km))
+    return km, n
+
+
+def search_by_bow_kf(desc1, angle1, valid1, fv1, desc2, angle2, valid2, fv2, nnratio, check_ori):
+    desc1, desc2, a1, a2, v1, v2 = _u8(desc1), _u8(desc2), _f32(angle1), _f32(angle2), _u8(valid1), _u8(valid2)
+    n1, o1, i1 = [_i32(a) for a in fv1]; n2, o2, i2 = [_i32(a) for a in fv2]
+    m12 = np.full(len(desc1), -1, np.int32)
+    n = lib().oro_search_by_bow_kf(_p(desc1), _p(a1), len(desc1), _p(v1), _p(n1), _p(o1), _p(i1), len(n1),
+                                   _p(desc2), _p(a2), len(desc2), _p(v2), _p(n2), _p(o2), _p(i2), len(n2), nnratio, int(check_ori), _p(m12))
+    return m12, n
+
+
+def search_for_triangulation(kps1, desc1, has_mp1, ur1, fv1, kps2, desc2, has_mp2, ur2, fv2, Cw, T2w, K2, F12, sf2, sigma2_2, only_stereo, check_ori):
+    kps1 = np.ascontiguousarray(kps1, KP_DTYPE); kps2 = np.ascontiguousarray(kps2, KP_DTYPE)
+    desc1, desc2, h1, h2, ur1, ur2 = _u8(desc1), _u8(desc2), _u8(has_mp1), _u8(has_mp2), _f32(ur1), _f32(ur2)
+    n1, o1, i1 = [_i32(a) for a in fv1]; n2, o2, i2 = [_i32(a) for a in fv2]
+    Cw, T2w, F12, sf2, s2 = _f32(Cw).reshape(3), _f32(T2w).reshape(16), _f32(F12).reshape(9), _f32(sf2), _f32(sigma2_2)
+    m12 = np.full(len(desc1), -1, np.int32)
+    fx, fy, cx, cy = K2
+    n = lib().oro_search_for_triangulation(_p(kps1), _p(desc1), len(desc1), _p(h1), _p(ur1), _p(n1), _p(o1), _p(i1), len(n1),
+                                           _p(kps2), _p(desc2), len(desc2), _p(h2), _p(ur2), _p(n2), _p(o2), _p(i2), len(n2),
+                                           _p(Cw), _p(T2w), fx, fy, cx, cy, _p(F12), _p(sf2), _p(s2), int(only_stereo), int(check_ori), _p(m12))
+    return m12, n
+
+
+def fuse(usable, xw, normal, min_inv, max_inv, mf_max, mp_desc, Tcw, Ow, K, bf, bounds, scale_factors, inv_sigma2, log_sf, grid, ur_kf, desc_kf, th):
+    usable, xw, normal, mn, mx, mf, mp_desc = _u8(usable), _f32(xw), _f32(normal), _f32(min_inv), _f32(max_inv), _f32(mf_max), _u8(mp_desc)
+    Tcw, Ow, b, sf, inv, ur_kf, desc_kf = _f32(Tcw).reshape(16), _f32(Ow).reshape(3), _f32(bounds), _f32(scale_factors), _f32(inv_sigma2), _f32(ur_kf), _u8(desc_kf)
+    bi = np.full(len(usable), -1, np.int32)
+    fx, fy, cx, cy = K
+    n = lib().oro_fuse(len(usable), _p(usable), _p(xw), _p(normal), _p(mn), _p(mx), _p(mf), _p(mp_desc), _p(Tcw), _p(Ow), fx, fy, cx, cy, bf, _p(b),
+                       _p(sf), _p(inv), len(sf), log_sf, C.byref(grid.g), _p(grid.kps), _p(ur_kf), _p(desc_kf), len(grid.kps), th, _p(bi))
+    return bi, n
+
+
+def fuse_sim3(usable, xw, normal, min_inv, max_inv, mf_max, mp_desc, Scw, K, bounds, scale_factors, log_sf, grid, desc_kf, th):
+    usable, xw, normal, mn, mx, mf, mp_desc = _u8(usable), _f32(xw), _f32(normal), _f32(min_inv), _f32(max_inv), _f32(mf_max), _u8(mp_desc)
+    Scw, b, sf, desc_kf = _f32(Scw).reshape(16), _f32(bounds), _f32(scale_factors), _u8(desc_kf)
+    bi = np.full(len(usable), -1, np.int32)
+    fx, fy, cx, cy = K
+    n = lib().oro_fuse_sim3(len(usable), _p(usable), _p(xw), _p(normal), _p(mn), _p(mx), _p(mf), _p(mp_desc), _p(Scw), fx, fy, cx, cy, _p(b),
+                            _p(sf), len(sf), log_sf, C.byref(grid.g), _p(grid.kps), _p(desc_kf), len(grid.kps), th, _p(bi))
+    return bi, n
+
+
+def search_by_sim3(side1, side2, K, s12, R12, t12, th):
+    """side = dict(usable, xw, min_inv, max_inv, mf_max, mp_desc, Tw, bounds, sf, log_sf, grid, desc) -> (match12, nfound)"""
+    keep = []
+
+    def args(sd):
+        a = [_u8(sd["usable"]), _f32(sd["xw"]), _f32(sd["min_inv"]), _f32(sd["max_inv"]), _f32(sd["mf_max"]), _u8(sd["mp_desc"]),
+             _f32(sd["Tw"]).reshape(16), _f32(sd["bounds"]), _f32(sd["sf"]), _u8(sd["desc"])]
+        keep.extend(a)
+        g = sd["grid"]
+        return [len(a[0]), _p(a[0]), _p(a[1]), _p(a[2]), _p(a[3]), _p(a[4]), _p(a[5]), _p(a[6]), _p(a[7]), _p(a[8]), len(a[8]), sd["log_sf"],
+                C.byref(g.g), _p(g.kps), _p(a[9])]
+    R12, t12 = _f32(R12).reshape(9), _f32(t12).reshape(3)
+    m12 = np.full(len(side1["usable"]), -1, np.int32)
+    fx, fy, cx, cy = K
+    n = lib().oro_search_by_sim3(*(args(side1) + args(side2) + [fx, fy, cx, cy, s12, _p(R12), _p(t12), th, _p(m12)]))
+    return m12, n
