@@ -243,6 +243,7 @@ typedef struct {
     float query_min_x, query_min_y;     /* (float)pKF->mnMinX, (float)pKF->mnMinY */
 } orbm_kf_grid;
 int orbm_reserve(orbm_matcher *m, int max_queries, int max_train, int max_pairs);
+int orbm_grid_count(const orbm_matcher *m);     /* keypoints in the handle's grid; -1: none (never built, or dropped by a growth) */
 int orbm_grid_build_kf(orbm_matcher *m, const orbx_keypoint *kps_un, int n, float assign_min_x, float assign_min_y,
                        float inv_w, float inv_h, float query_min_x, float query_min_y);
 

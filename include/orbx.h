@@ -121,6 +121,8 @@ int orbx_extract_batch_device(orbx_extractor *h, const uint8_t *d_images, int nf
  * (w+38) x (h+38) reflect-101 bordered buffer (src/ORBextractor.cc:1115-1133). */
 int orbx_level_size(const orbx_extractor *h, int level, int *width, int *height);
 int orbx_download_level(orbx_extractor *h, int frame, int level, uint8_t *dst, int dst_stride, int border);
+/* All levels at once (one synchronisation): dst[l] / dst_stride[l] per level, sized (w_l + 2*border) x (h_l + 2*border). */
+int orbx_download_pyramid(orbx_extractor *h, int frame, uint8_t *const *dst, const int *dst_stride, int border);
 
 /* Debug/parity taps for the last call (host copies): FAST candidates of one level before the
  * quadtree, as (x, y, response) int32 triples in unspecified order.  Returns the count or < 0. */

@@ -80,6 +80,8 @@ def lib():
     L.orbx_extract_batch_device.argtypes = [vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_size_t, vp, vp, C.c_int, vp, vp, vp]
     L.orbx_level_size.argtypes = [vp, C.c_int, ip, ip]
     L.orbx_download_level.argtypes = [vp, C.c_int, C.c_int, vp, C.c_int, C.c_int]
+    L.orbx_download_pyramid.argtypes = [vp, C.c_int, vp, vp, C.c_int]
+    L.orbx_download_pyramid.restype = C.c_int
     L.orbx_download_candidates.argtypes = [vp, C.c_int, C.c_int, vp, C.c_int]
     L.orbx_last_stage_ms.argtypes = [vp, vp]
     L.orbx_set_profiling.argtypes = [vp, C.c_int]
@@ -340,7 +342,10 @@ class ORBextractor:
 
     def extract_batch_raw(self, images):
         """orbx_extract_batch without the per-frame slicing: (kps [B,cap], desc [B,cap,32], counts [B]).  A row / frame
-        pitch larger than the width (a view into a bigger array) is passed through as it is."""
+        pitch larger than the width (a view into a bigger array) is passed through as it is.
+        The three arrays are this object's reusable buffers (the zero-allocation benchmark path): the next call with the same
+        batch size overwrites them in place, so copy what must survive it; rows at and beyond counts[f] are stale data of
+        earlier calls."""
         images = np.asarray(images, dtype=np.uint8)
         if images.strides[2] != 1 or images.strides[1] < images.shape[2] or images.strides[0] < images.strides[1] * (images.shape[1] - 1) + images.shape[2]:
             images = np.ascontiguousarray(images)
@@ -371,6 +376,17 @@ class ORBextractor:
             a = np.zeros((h + 2 * border, w + 2 * border), np.uint8)
             _chk(self.L.orbx_download_level(self.h, frame, l, _p(a), a.strides[0], border))
             out.append(a)
+        return out
+
+    def image_pyramid_all(self, frame=0, border=19):
+        """All levels in one call (orbx_download_pyramid: one synchronisation), with the reference's 19-px reflect-101 border."""
+        out = []
+        for l in range(self.nlevels):
+            w, h = self.level_size(l)
+            out.append(np.zeros((h + 2 * border, w + 2 * border), np.uint8))
+        ptrs = (C.c_void_p * self.nlevels)(*[a.ctypes.data for a in out])
+        strides = (C.c_int * self.nlevels)(*[a.strides[0] for a in out])
+        _chk(self.L.orbx_download_pyramid(self.h, frame, ptrs, strides, border))
         return out
 
     def candidates(self, frame, level, cap=1 << 20):

@@ -299,6 +299,9 @@ extern "C" int orbm_grid_build(orbm_matcher *m, const orbx_keypoint *kps_un, int
     return ORBX_OK;
 }
 
+// number of keypoints in the handle's grid, -1 when there is none (never built, or dropped by a workspace growth)
+extern "C" int orbm_grid_count(const orbm_matcher *m) { return (m && m->grid_ok) ? m->grid.n : -1; }
+
 // A key frame's grid.  KeyFrame copies mGrid from the Frame it was made of (src/KeyFrame.cc:48-54), so the cells were filled by
 // Frame::PosInGrid with Frame's float mnMinX / mnMinY and mfGridElementWidthInv / HeightInv (src/Frame.cc:382-392: assign_*, inv_*),
 // while KeyFrame::GetFeaturesInArea (src/KeyFrame.cc:569-606) subtracts the key frame's own mnMinX / mnMinY, which are ints

@@ -122,6 +122,7 @@ struct orbx_extractor {
     // current plan
     int cur_w = 0, cur_h = 0; int last_batch = 0;
     const uint8_t *last_input = nullptr; int last_in_stride = 0; long long last_in_frame = 0;
+    uint8_t *h_pyr = nullptr; size_t h_pyr_bytes = 0;      // page-locked staging of orbx_download_pyramid (lazy)
     OrbxPlan plan; OrbxWork work; ResizeTab tabs[ORBX_MAX_LEVELS]; int area2[ORBX_MAX_LEVELS];
     // several pyramid levels per launch (k_resize_fused): one plan per band height (16 rows for batches, 8 for a few frames)
     struct FusePlan { bool ok = false; int a = 0, b = 0, nbands = 0, buf0 = 0, lds = 0, bh = 0; size_t off = 0; } fuse[2];
@@ -288,6 +289,7 @@ static void free_all(orbx_extractor *h)
 {
     if (!h) return;
     hipSetDevice(h->device);
+    (void)hipHostFree(h->h_pyr);
     hipFree(h->d_input); hipFree(h->d_pyr); hipFree(h->d_tab_i); hipFree(h->d_tab_s); hipFree(h->d_cells); hipFree(h->d_bands);
     hipFree(h->work.cand); hipFree(h->work.cand_count); hipFree(h->work.owner); hipFree(h->work.arena);
     hipFree(h->work.sel); hipFree(h->work.nk); hipFree(h->work.ncand); hipFree(h->work.errflags);
@@ -1106,6 +1108,52 @@ extern "C" int orbx_download_level(orbx_extractor *h, int frame, int level, uint
             for (int x = 1; x <= border; x++) {
                 drow[-x] = srow[reflect101_host(-x, L.w)];
                 drow[L.w - 1 + x] = srow[reflect101_host(L.w - 1 + x, L.w)];
+            }
+        }
+    }
+    return ORBX_OK;
+}
+
+// Every level of frame `frame` of the last call in one go: one asynchronous copy per level into a page-locked staging block, ONE
+// synchronisation, then the rows are laid out in the caller's buffers and the reflect-101 border is rebuilt on the host
+// (src/ORBextractor.cc:1115-1133).  This is what keeps ORBextractor::mvImagePyramid valid after every operator() in the adapter.
+extern "C" int orbx_download_pyramid(orbx_extractor *h, int frame, uint8_t *const *dst, const int *dst_stride, int border)
+{
+    if (!h || !dst || !dst_stride || h->cur_w == 0 || frame < 0 || frame >= h->last_batch || border < 0)
+        return fail(ORBX_E_INVALID, "bad download_pyramid argument");
+    HIPCHK(hipSetDevice(h->device));
+    size_t need = 0, off[ORBX_MAX_LEVELS];
+    for (int l = 0; l < h->nlevels; l++) {
+        const OrbxLevel &L = h->plan.lv[l];
+        if (!dst[l] || dst_stride[l] < L.w + 2 * border) return fail(ORBX_E_INVALID, "level %d: NULL buffer or dst_stride too small", l);
+        off[l] = need;
+        need += ((size_t)L.w * L.h + 255) & ~(size_t)255;
+    }
+    if (need > h->h_pyr_bytes) {
+        (void)hipHostFree(h->h_pyr); h->h_pyr = nullptr; h->h_pyr_bytes = 0;
+        HIPCHK(hipHostMalloc((void **)&h->h_pyr, need + need / 4));
+        h->h_pyr_bytes = need + need / 4;
+    }
+    HIPCHK(hipDeviceSynchronize());   // the last call may have run on a caller stream and the aux streams
+    for (int l = 0; l < h->nlevels; l++) {
+        OrbxLevel L = h->plan.lv[l];
+        if (l == 0) { L.base = const_cast<uint8_t *>(h->last_input); L.stride = h->last_in_stride; L.frame_stride = h->last_in_frame; }
+        HIPCHK(hipMemcpy2DAsync(h->h_pyr + off[l], (size_t)L.w, L.base + (size_t)frame * L.frame_stride, L.stride, L.w, L.h, hipMemcpyDeviceToHost, h->stream));
+    }
+    HIPCHK(hipStreamSynchronize(h->stream));
+    for (int l = 0; l < h->nlevels; l++) {
+        const OrbxLevel &L = h->plan.lv[l];
+        const int ds = dst_stride[l];
+        uint8_t *interior = dst[l] + (size_t)border * ds + border;
+        for (int y = 0; y < L.h; y++) memcpy(interior + (size_t)y * ds, h->h_pyr + off[l] + (size_t)y * L.w, (size_t)L.w);
+        if (border > 0) {             // copyMakeBorder(..., BORDER_REFLECT_101), :1127-1133
+            for (int y = 0; y < L.h; y++) {
+                uint8_t *row = interior + (size_t)y * ds;
+                for (int x = 1; x <= border; x++) { row[-x] = row[reflect101_host(-x, L.w)]; row[L.w - 1 + x] = row[reflect101_host(L.w - 1 + x, L.w)]; }
+            }
+            for (int y = 1; y <= border; y++) {
+                memcpy(interior - (ptrdiff_t)y * ds - border, interior + (ptrdiff_t)reflect101_host(-y, L.h) * ds - border, (size_t)L.w + 2 * border);
+                memcpy(interior + (ptrdiff_t)(L.h - 1 + y) * ds - border, interior + (ptrdiff_t)reflect101_host(L.h - 1 + y, L.h) * ds - border, (size_t)L.w + 2 * border);
             }
         }
     }

@@ -8,8 +8,12 @@
 // what the repo's tests compile.
 //
 // Differences a maintainer should know:
-//   * mvImagePyramid is filled lazily by FetchImagePyramid() (a D2H copy per level); only
-//     Frame::ComputeStereoMatches reads it (src/Frame.cc:473,563,580).
+//   * mvImagePyramid is valid after every operator(), as in the reference (include/ORBextractor.h:85; read by
+//     Frame::ComputeStereoMatches, src/Frame.cc:473,563,580): each level is a view of the interior of a
+//     (w + 38) x (h + 38) buffer with the 19-px reflect-101 border (src/ORBextractor.cc:1115-1133), downloaded
+//     after the extraction in one synchronisation (orbx_download_pyramid).  A caller that never reads it on the
+//     host (monocular tracking; stereo through orbx_stereo_matches, which reads the levels on the device)
+//     switches the download off with SetHostPyramid(false) and may still call FetchImagePyramid() on demand.
 //   * The handle is sized for the largest image seen so far (it starts at 1920x1080 and grows on demand).
 //   * Failures of the GPU layer, and an image that is not CV_8UC1 (the reference asserts, :1052), produce an
 //     empty result, the reference's only failure mode (src/ORBextractor.cc:1048-1049); the text is in LastError().
@@ -57,6 +61,7 @@ public:
         const int rc = orbx_extract(h_, image.data, image.cols, image.rows, (int)image.step, kp_.data(), desc_.data(), cap_, &n);
         if (rc != ORBX_OK) { err_ = orbx_last_error(); _descriptors.release(); return; }
         fill(n, _keypoints, _descriptors);
+        if (hostPyramid_) FetchImagePyramid();                           // ComputePyramid's side effect, :1055
     }
 
     // operator() in two halves (orbx_extract_begin / orbx_extract_end): Begin returns as soon as the image is staged and the
@@ -80,6 +85,7 @@ public:
         const int rc = orbx_extract_end(h_, kp_.data(), desc_.data(), cap_, &n);
         if (rc != ORBX_OK) { err_ = orbx_last_error(); _descriptors.release(); return; }
         fill(n, _keypoints, _descriptors);
+        if (hostPyramid_) FetchImagePyramid();
     }
 
     int inline GetLevels() { return nlevels_; }
@@ -89,17 +95,25 @@ public:
     std::vector<float> inline GetScaleSigmaSquares() { return mvLevelSigma2; }
     std::vector<float> inline GetInverseScaleSigmaSquares() { return mvInvLevelSigma2; }
 
-    // include/ORBextractor.h:85.  Call FetchImagePyramid() after operator() when the pyramid is needed on the host.
+    // include/ORBextractor.h:85: valid after every operator() (End()), unless SetHostPyramid(false)
     std::vector<cv::Mat> mvImagePyramid;
+    void SetHostPyramid(bool on) { hostPyramid_ = on; }
     bool FetchImagePyramid()
     {
         if (!h_) return false;
+        const int B = 19;                                                // EDGE_THRESHOLD, src/ORBextractor.cc:76
+        std::vector<unsigned char *> dst(nlevels_);
+        std::vector<int> stride(nlevels_);
+        if ((int)pyrStore_.size() != nlevels_) pyrStore_.resize(nlevels_);
         for (int l = 0; l < nlevels_; l++) {
             int w = 0, hgt = 0;
-            if (orbx_level_size(h_, l, &w, &hgt) != ORBX_OK) return false;
-            mvImagePyramid[l].create(hgt, w, CV_8UC1);
-            if (orbx_download_level(h_, 0, l, mvImagePyramid[l].data, (int)mvImagePyramid[l].step, 0) != ORBX_OK) return false;
+            if (orbx_level_size(h_, l, &w, &hgt) != ORBX_OK) { err_ = orbx_last_error(); return false; }
+            pyrStore_[l].create(hgt + 2 * B, w + 2 * B, CV_8UC1);        // :1115-1117: temp(sz + 2*EDGE_THRESHOLD)
+            dst[l] = pyrStore_[l].data; stride[l] = (int)pyrStore_[l].step;
+            // mvImagePyramid[level] = temp(Rect(EDGE_THRESHOLD, EDGE_THRESHOLD, sz.width, sz.height)): a view of the interior
+            mvImagePyramid[l] = cv::Mat(hgt, w, CV_8UC1, pyrStore_[l].data + (size_t)B * pyrStore_[l].step + B, pyrStore_[l].step);
         }
+        if (orbx_download_pyramid(h_, 0, dst.data(), stride.data(), B) != ORBX_OK) { err_ = orbx_last_error(); return false; }
         return true;
     }
     orbx_extractor *handle() { return h_; }   // for orbx_stereo_matches (Frame::ComputeStereoMatches)
@@ -150,6 +164,8 @@ protected:
     std::vector<orbx_keypoint> kp_;
     std::vector<unsigned char> desc_;
     std::vector<float> mvScaleFactor, mvInvScaleFactor, mvLevelSigma2, mvInvLevelSigma2;
+    std::vector<cv::Mat> pyrStore_;     // the bordered level buffers mvImagePyramid's views point into
+    bool hostPyramid_ = true;
     std::string err_;
 };
 

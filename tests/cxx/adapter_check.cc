@@ -72,7 +72,6 @@ int main(int argc, char **argv)
     matcher.BestTwo(descriptors, descriptors, nullptr, nullptr, bi, bd, sd);
     int self = 0;
     for (size_t i = 0; i < bi.size(); i++) self += (bd[i] == 0);
-    extractor.FetchImagePyramid();
     // a 3-channel / float image is not CV_8UC1: empty result (the reference asserts, src/ORBextractor.cc:1052)
     std::vector<cv::KeyPoint> keysF;
     cv::Mat descF, imF(H, W, CV_32FC1);
@@ -86,8 +85,23 @@ int main(int argc, char **argv)
     extractor(big, cv::Mat(), keysB, descB);
     const int grew = keysB.size() > 900 && descB.rows == (int)keysB.size();
     extractor(im, cv::Mat(), keys, descriptors);
-    extractor.FetchImagePyramid();
-    printf("%zu %016llx %d %d %d %d %d\n", keys.size(), h, self, extractor.mvImagePyramid[7].cols,
-           ORB_SLAM2::ORBmatcher::DescriptorDistance(descriptors.row(0), descriptors.row(1)), rejected, grew);
+    // mvImagePyramid is valid after operator() (include/ORBextractor.h:85), as Frame::ComputeStereoMatches needs it (src/Frame.cc:473,563,580):
+    // level 0's interior is the image, one step outside the interior is the reflect-101 border, every level hashes to what the C ABI returns
+    int pyr_ok = (int)extractor.mvImagePyramid.size() == 8 && extractor.mvImagePyramid[0].rows == H && extractor.mvImagePyramid[0].cols == W;
+    unsigned long long hp = 1469598103934665603ull;
+    for (int l = 0; pyr_ok && l < 8; l++) {
+        const cv::Mat &lv = extractor.mvImagePyramid[l];
+        for (int y = 0; y < lv.rows; y++) {
+            const unsigned char *row = lv.ptr<unsigned char>(y);
+            for (int x = 0; x < lv.cols; x++) { hp ^= row[x]; hp *= 1099511628211ull; }
+            pyr_ok = pyr_ok && row[-1] == row[1] && row[-19] == row[19] && row[lv.cols] == row[lv.cols - 2];
+        }
+        const unsigned char *r0 = lv.ptr<unsigned char>(0);
+        pyr_ok = pyr_ok && !memcmp(r0 - (ptrdiff_t)lv.step - 19, lv.ptr<unsigned char>(1) - 19, (size_t)lv.cols + 38) &&
+                 !memcmp(lv.ptr<unsigned char>(lv.rows - 1) + (ptrdiff_t)19 * (ptrdiff_t)lv.step - 19, lv.ptr<unsigned char>(lv.rows - 20) - 19, (size_t)lv.cols + 38);
+    }
+    for (int y = 0; pyr_ok && y < H; y++) pyr_ok = !memcmp(extractor.mvImagePyramid[0].ptr<unsigned char>(y), im.ptr<unsigned char>(y), (size_t)W);
+    printf("%zu %016llx %d %d %d %d %d %d %016llx\n", keys.size(), h, self, extractor.mvImagePyramid[7].cols,
+           ORB_SLAM2::ORBmatcher::DescriptorDistance(descriptors.row(0), descriptors.row(1)), rejected, grew, pyr_ok, hp);
     return 0;
 }

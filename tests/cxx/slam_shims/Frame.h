@@ -61,6 +61,7 @@ public:
     float mfScaleFactor, mfLogScaleFactor;
     std::vector<float> mvScaleFactors, mvInvScaleFactors, mvLevelSigma2, mvInvLevelSigma2;
     inline static float mnMinX = 0, mnMaxX = 0, mnMinY = 0, mnMaxY = 0;
+    inline static float mfGridElementWidthInv = 0, mfGridElementHeightInv = 0;
 };
 
 // MapPoint::PredictScale(dist, Frame*) with the reference's arithmetic (src/MapPoint.cc:402-417): float ratio, log of a float, ceil

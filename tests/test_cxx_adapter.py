@@ -23,7 +23,7 @@ def _build(orbx, src, out):
 
 
 def test_adapters_compile_and_link(orbx, tmp_path):
-    for src in ("adapter_check.cc", "tracking_callsites.cc"):
+    for src in ("adapter_check.cc", "tracking_callsites.cc", "mapping_callsites.cc"):
         exe = _build(orbx, src, str(tmp_path / src[:-3]))
         assert subprocess.run([exe, "compile-only"]).returncode == 0
 
@@ -74,6 +74,14 @@ def test_adapter_equals_cabi(orbx, synth, tmp_path):
     assert int(out[4]) == orbx.ORBmatcher.DescriptorDistance(desc[0], desc[1])
     assert int(out[5]) == 1                   # a non-CV_8UC1 image gives the empty result
     assert int(out[6]) == 1                   # an image larger than the handle's first size is extracted, not refused
+    assert int(out[7]) == 1                   # mvImagePyramid is valid after operator(): interior views of reflect-101 bordered buffers
+    ex = orbx.ORBextractor(1000, max_width=640, max_height=480)
+    ex(img)
+    hp = 1469598103934665603
+    for lvl in ex.image_pyramid():
+        for b in lvl.tobytes():
+            hp = ((hp ^ b) * 1099511628211) & 0xFFFFFFFFFFFFFFFF
+    assert out[8] == "%016x" % hp             # ... whose pixels are the ones the C ABI's per-level download returns
 
 
 @pytest.mark.gpu
@@ -97,3 +105,26 @@ def test_tracking_callsites_equal_cabi(orbx, synth, tmp_path):
         assert int(rows[name][1]) == 1, "%s differs from the C ABI" % name
         assert int(rows[name][0]) >= floor, "%s: only %s matches" % (name, rows[name][0])
     assert float(rows["construct_ns"][0]) < 1000.0
+
+
+@pytest.mark.gpu
+def test_mapping_callsites_equal_cabi(orbx, synth, tmp_path):
+    """The reference's LocalMapping / LoopClosing call expressions (SearchForTriangulation, Fuse x 2, SearchByBoW(KF, KF), SearchBySim3,
+    SearchByProjection(KF, Scw)) on the drop-in class == direct C-ABI calls (which tests/test_kf_matchers.py ties to the oracle); for
+    the Fuse variants the object graph after the call equals a replay of the reference's bookkeeping on the C ABI's match table."""
+    import test_vocabulary as TV
+    exe = _build(orbx, "mapping_callsites.cc", str(tmp_path / "mapping_callsites"))
+    W, H = 1241, 376
+    frames, layer = synth.stream_layers(5, W, H, 2, shifts=(2, 4, 6))
+    frames.tofile(tmp_path / "frames.u8"); layer.astype(np.uint8).tofile(tmp_path / "layer.u8")
+    voc = str(tmp_path / "voc.txt")
+    TV.make_vocabulary(voc, k=8, depth=3, seed=5)
+    p = subprocess.run([exe, str(tmp_path / "frames.u8"), str(tmp_path / "layer.u8"), str(W), str(H), voc], capture_output=True, text=True)
+    assert p.returncode == 0, p.stdout + p.stderr
+    rows = {ln.split()[0]: ln.split()[1:] for ln in p.stdout.splitlines() if ln.strip()}
+    want = {"SearchForTriangulation": 40, "SearchByBoW(KF,KF)": 30, "SearchBySim3": 100, "SearchByProjection(KF,Scw)": 100, "Fuse(KF,Scw)": 100,
+            "Fuse(KF,points)": 100, "Fuse(KF,candidates)": 20}
+    for name, floor in want.items():
+        assert name in rows, p.stdout
+        assert int(rows[name][1]) == 1, "%s differs from the C ABI\n%s" % (name, p.stdout)
+        assert int(rows[name][0]) >= floor, "%s: only %s\n%s" % (name, rows[name][0], p.stdout)

@@ -268,6 +268,13 @@ def test_pyramid_border_download(orbx, synth):
     opyr = O.Extractor(300).pyramid(img)
     for l in range(8):
         assert np.array_equal(pyr[l], np.pad(opyr[l], 19, mode="reflect"))     # copyMakeBorder REFLECT_101
+    allp = ex.image_pyramid_all(border=19)                                      # one call, one synchronisation (the adapter's mvImagePyramid)
+    assert all(np.array_equal(a, b) for a, b in zip(allp, pyr))
+    assert all(np.array_equal(a, b) for a, b in zip(ex.image_pyramid_all(border=0), opyr))
+    ex2 = orbx.ORBextractor(300, max_width=320, max_height=240, max_batch=2)
+    ex2.extract_batch(np.stack([img, img[::-1].copy()]))
+    flipped = ex2.image_pyramid_all(frame=1, border=19)
+    assert np.array_equal(flipped[0][19:-19, 19:-19], img[::-1]) and not np.array_equal(flipped[1], pyr[1])
 
 
 def test_ring_profiling_mode(orbx, synth):
