@@ -547,9 +547,15 @@ static int pick_splits(int nq_cap, int nbatch, int nt_hint)
     while (S > 1 && nt_hint / S < 16) S--;       // keep >= 16 train descriptors per split
     return S;
 }
-static int ensure_partials(orbm_matcher *m, size_t need)
+static int ensure_partials(orbm_matcher *m, size_t need, hipStream_t s = nullptr)
 {
     if (need <= m->part_elems) return ORBX_OK;
+    {   // growing means synchronise + free + allocate: not inside a stream capture (warm the handle up with the same arguments first)
+        hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
+        if (s && hipStreamIsCapturing(s, &st) == hipSuccess && st == hipStreamCaptureStatusActive)
+            return mfail(ORBX_E_INVALID, "the matcher's partial buffer must grow (%zu -> %zu pairs) while the stream is being captured: run the call once outside the capture", m->part_elems, need);
+        (void)hipGetLastError();
+    }
     MHIPCHK(hipDeviceSynchronize());
     (void)hipFree(m->d_part);
     m->d_part = nullptr; m->part_elems = 0;
@@ -640,7 +646,7 @@ static int launch_dense_batch(orbm_matcher *m, const uint8_t *d_q, const int32_t
                               const int32_t *d_nt, int cap, int nbatch, hipStream_t s, int *S_out)
 {
     const int S = m->dense_popcount ? pick_splits(cap, nbatch, cap) : orbm_mfma_splits(cap, cap, nbatch);
-    int rc = ensure_partials(m, (size_t)(S + 1) * nbatch * cap);     // + one slot per query for k_merge_keys
+    int rc = ensure_partials(m, (size_t)(S + 1) * nbatch * cap, s);     // + one slot per query for k_merge_keys
     if (rc != ORBX_OK) return rc;
     if (m->dense_popcount)
         hipLaunchKernelGGL(k_best2_dense, dim3((cap + M_THREADS - 1) / M_THREADS, nbatch, S), dim3(M_THREADS), 0, s,

@@ -237,7 +237,8 @@ int orbm_mfma_splits(int nq_cap, int nt_cap, int nbatch)
     const int ttiles = std::max((nt_cap + 31) >> 5, 1);
     const long long wgs = (long long)nbatch * ((((nq_cap + 31) >> 5) + 4 * MF_QB - 1) / (4 * MF_QB));
     int S = (int)std::max<long long>((768 + wgs - 1) / std::max<long long>(wgs, 1), 1);
-    if (const char *e = getenv("ORBM_MFMA_SPLITS")) S = std::max(atoi(e), 1);   // tuning switch
+    static const int forced = [] { const char *e = getenv("ORBM_MFMA_SPLITS"); return e ? std::max(atoi(e), 1) : 0; }();   // tuning switch, read once
+    if (forced) S = forced;
     S = std::min(S, std::max(ttiles / (2 * MF_STG), 1));
     return std::min(S, 64);
 }

@@ -19,69 +19,7 @@
 
 #include "orbx_internal.h"
 
-// A few helper threads for the host side of orbx_extract_batch: repacking 64 frames into the pinned staging buffer is ~20 MB
-// of memcpy, which one core moves slower than PCIe gen5 does.  Workers keep polling for ~0.3 ms after a job (the chunks of one
-// batch arrive back to back), then sleep on a condition variable.
-class StagePool {
-public:
-    explicit StagePool(int nthreads)
-    {
-        for (int i = 0; i < nthreads; i++) th_.emplace_back([this] { worker(); });
-    }
-    ~StagePool()
-    {
-        { std::lock_guard<std::mutex> lk(mu_); quit_ = true; gen_.fetch_add(1); }
-        cv_.notify_all();
-        for (auto &t : th_) t.join();
-    }
-    // fn(i) for i in [0, n), spread over the workers and the calling thread; returns when all are done
-    void parallel_for(int n, const std::function<void(int)> &fn)
-    {
-        if (n <= 0) return;
-        if (th_.empty() || n == 1) { for (int i = 0; i < n; i++) fn(i); return; }
-        fn_ = &fn; n_ = n; next_.store(0); left_.store(n);
-        { std::lock_guard<std::mutex> lk(mu_); gen_.fetch_add(1); }
-        cv_.notify_all();
-        drain();
-        while (left_.load(std::memory_order_acquire) > 0) std::this_thread::yield();
-    }
-private:
-    void drain()
-    {
-        for (;;) {
-            const int i = next_.fetch_add(1);
-            if (i >= n_) return;
-            (*fn_)(i);
-            left_.fetch_sub(1, std::memory_order_release);
-        }
-    }
-    void worker()
-    {
-        unsigned long long seen = 0;
-        for (;;) {
-            const auto t0 = std::chrono::steady_clock::now();
-            while (gen_.load(std::memory_order_acquire) == seen) {        // poll first, sleep later
-                if (std::chrono::steady_clock::now() - t0 > std::chrono::microseconds(300)) {
-                    std::unique_lock<std::mutex> lk(mu_);
-                    cv_.wait(lk, [&] { return gen_.load() != seen; });
-                    break;
-                }
-                std::this_thread::yield();
-            }
-            seen = gen_.load(std::memory_order_acquire);
-            if (quit_) return;
-            drain();
-        }
-    }
-    std::vector<std::thread> th_;
-    std::mutex mu_;
-    std::condition_variable cv_;
-    std::atomic<unsigned long long> gen_{0};
-    std::atomic<int> next_{0}, left_{0};
-    const std::function<void(int)> *fn_ = nullptr;
-    int n_ = 0;
-    bool quit_ = false;
-};
+#include "stage_pool.h"
 
 static thread_local std::string g_err;
 static int fail(int code, const char *fmt, ...)
@@ -123,6 +61,7 @@ struct orbx_extractor {
     int cur_w = 0, cur_h = 0; int last_batch = 0;
     const uint8_t *last_input = nullptr; int last_in_stride = 0; long long last_in_frame = 0;
     uint8_t *h_pyr = nullptr; size_t h_pyr_bytes = 0;      // page-locked staging of orbx_download_pyramid (lazy)
+    const uint8_t *pin_ptr = nullptr; int pin_n = 0; size_t pin_stride = 0, pin_bytes = 0; bool pin_is = false;   // last is_pinned_host() answer
     OrbxPlan plan; OrbxWork work; ResizeTab tabs[ORBX_MAX_LEVELS]; int area2[ORBX_MAX_LEVELS];
     // several pyramid levels per launch (k_resize_fused): one plan per band height (16 rows for batches, 8 for a few frames)
     struct FusePlan { bool ok = false; int a = 0, b = 0, nbands = 0, buf0 = 0, lds = 0, bh = 0; size_t off = 0; } fuse[2];
@@ -726,7 +665,7 @@ extern "C" int orbx_extract_batch_device(orbx_extractor *h, const uint8_t *d_ima
 // costs ~3 ms; this and ONE contiguous copy cost ~0.1 ms); rows are dealt to the staging threads in blocks
 // Is [p, p + bytes) page-locked host memory (hipHostMalloc / hipHostRegister)?  Then the DMA engine can read it where it lies and
 // the repack into the handle's pinned staging block -- 0.23 ms of the calling thread for 64 VGA frames -- is skipped.
-static bool is_pinned_host(const void *p, size_t bytes)
+static bool is_pinned_range(const void *p, size_t bytes)
 {
     hipPointerAttribute_t a0, a1;
     if (hipPointerGetAttributes(&a0, p) != hipSuccess || hipPointerGetAttributes(&a1, (const uint8_t *)p + bytes - 1) != hipSuccess) {
@@ -734,6 +673,15 @@ static bool is_pinned_host(const void *p, size_t bytes)
         return false;
     }
     return a0.type == hipMemoryTypeHost && a1.type == hipMemoryTypeHost;
+}
+// every frame's first and last byte is checked: frames carved out of several page-locked allocations with pageable gaps between
+// them would pass a test of the block's two ends only (the copies are issued per frame or per chunk, never across such a gap
+// unless the frames are contiguous -- and contiguous frames inside one registered range are what the per-frame test confirms)
+static bool is_pinned_host(const uint8_t *images, int nframes, size_t frame_stride, size_t frame_bytes)
+{
+    for (int k = 0; k < nframes; k++)
+        if (!is_pinned_range(images + (size_t)k * frame_stride, frame_bytes)) return false;
+    return true;
 }
 
 // upload frames [k0, k1) straight from the caller's page-locked buffer into the handle's input block (rows are re-pitched by the copy)
@@ -860,7 +808,7 @@ extern "C" int orbx_extract_batch(orbx_extractor *h, const uint8_t *images, int 
     if (width > h->max_w || height > h->max_h) return fail(ORBX_E_SHAPE, "frame %dx%d exceeds the handle's max %dx%d", width, height, h->max_w, h->max_h);
     HIPCHK(hipSetDevice(h->device));
     if (!h->pool && nframes >= 8) {                         // staging threads: up to 6, leaving cores to the caller
-        const unsigned hc = std::thread::hardware_concurrency();
+        const unsigned hc = (unsigned)StagePool::usable_cpus();       // affinity mask and cgroup quota, not the machine's core count
         h->pool = new StagePool((int)std::min<unsigned>(6u, hc > 2 ? hc / 2 - 1 : 0u));
     }
     // Chunked pipeline ("host-buffer batches"): while chunk c is uploaded and extracted, chunk c + 1 is repacked by the
@@ -932,7 +880,14 @@ extern "C" int orbx_extract_batch(orbx_extractor *h, const uint8_t *images, int 
     }
     // page-locked caller memory is uploaded where it lies (ORBX_BATCH_PINNED=0 keeps the staging copy: A/B switch)
     static const bool pinned_ok = [] { const char *e = getenv("ORBX_BATCH_PINNED"); return !e || atoi(e) != 0; }();
-    const bool pinned_in = pinned_ok && is_pinned_host(images, (size_t)(nframes - 1) * frame_stride + (size_t)(height - 1) * row_stride + width);
+    // the answer for one buffer is remembered (a capture pipeline hands over the same page-locked block again and again; should it
+    // have been unregistered meanwhile, the copies below are still correct -- the runtime stages them -- only slower)
+    const size_t frame_bytes = (size_t)(height - 1) * row_stride + width;
+    if (pinned_ok && !(h->pin_ptr == images && h->pin_n == nframes && h->pin_stride == frame_stride && h->pin_bytes == frame_bytes)) {
+        h->pin_ptr = images; h->pin_n = nframes; h->pin_stride = frame_stride; h->pin_bytes = frame_bytes;
+        h->pin_is = is_pinned_host(images, nframes, frame_stride, frame_bytes);
+    }
+    const bool pinned_in = pinned_ok && h->pin_is;
     double t_stage = 0, t_launch = 0;
     const double t_begin = trace ? now() : 0;
     for (int c = 0; c < nch; c++) {
