@@ -43,7 +43,7 @@ def parse_args(argv=None):
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-pipelined", action="store_true", help="skip the extra two-stream / HIP-graph throughput pass")
     ap.add_argument("--no-host-api", action="store_true", help="skip the host-buffer API (PCIe inclusive) measurement")
-    ap.add_argument("--no-extra-configs", action="store_true", help="skip the 8x1920x1080 n=4000 extract+match step (BASELINE configs[2])")
+    ap.add_argument("--no-extra-configs", action="store_true", help="skip the other BASELINE configs (one 640x480 frame, 8x1920x1080 n=4000 extract+match, the 1241x376 tracking loop) and the realistic-density stream")
     ap.add_argument("--pipelined-streams", type=int, default=2)
     ap.add_argument("--cpu-budget", type=float, default=12.0)
     return ap.parse_args(argv)
@@ -329,6 +329,127 @@ def extra_config3(pkg, torch, shard, synth, device, steps=20, warmup=3):
             "whole_path_algorithmic_GBps": round(whole, 1), "frac_of_hbm_peak": round(whole / 8000.0, 4)}
 
 
+def extra_survey_stream(pkg, torch, shard, synth, device, steps=20, warmup=3):
+    """The headline step (64 x 640x480, n = 1000, extract + match) on SURVEY.md 8(d)'s texture AS WRITTEN (16-px blocks, 0.002*W*H
+    rectangles of 8..64 px, one 3x3 box blur): about half the corner density of the headline stream, whose texture is corner-dense
+    on purpose.  FAST's second stage and the quadtree scale with that density."""
+    import numpy as np
+    W, H, NF, B = 640, 480, 1000, 64
+    frames = torch.from_numpy(synth.stream_survey(4, W, H, B)).cuda()
+    st = torch.cuda.Stream()
+    p = DevicePath(pkg, torch, shard, frames, W, H, B, NF, device, True, stream=st)
+    with torch.cuda.stream(st):
+        for _ in range(warmup):
+            p.step()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            p.step()
+        torch.cuda.synchronize()
+        el = (time.perf_counter() - t0) / steps
+    _, _, _, counts, nmatch = p.layout.views(p.bufs[0])
+    if int(p.status.abs().sum().item()) != 0:
+        raise RuntimeError("device status nonzero")
+    nk = int(counts[1:].sum().item())
+    p.ex.set_profiling(True)
+    acc = np.zeros(4)
+    for _ in range(3):
+        p.extract_into(p.bufs[0], st.cuda_stream)
+        acc += p.ex.stage_ms()
+    p.ex.set_profiling(False)
+    acc /= 3
+    ncand = sum(len(p.ex.candidates(0, l)) for l in range(8))
+    return {"workload": "64 x 640x480 nFeatures=1000, extract + dense match vs previous frame on SURVEY.md 8(d)'s texture as written "
+                        "(realistic corner density), resident in HBM",
+            "steps": steps, "ms_per_step": round(el * 1e3, 4), "frames_per_s": round(B / el, 1), "keypoints_per_s": round(nk / el, 1),
+            "keypoints_per_frame": round(nk / B, 1), "fast_candidates_per_frame": ncand, "matches_per_step": int(nmatch[2:].sum().item()),
+            "stage_ms": {k: round(float(v), 4) for k, v in zip(("pyramid", "fast", "quadtree", "describe"), acc)}}
+
+
+def extra_single_frame(pkg, torch, synth, device, reps=200):
+    """BASELINE configs[1] as written: ONE 640x480 frame, nFeatures = 1000.  Latency (p50 / p90) of (a) the device-resident call
+    (frame already in HBM, results stay there: one synchronisation per call) and (b) the reference's own call shape, host image in,
+    host keypoints + descriptors out (orbx_extract on a one-frame handle: upload, ten kernels and download are one HIP graph), PCIe
+    inclusive."""
+    import numpy as np
+    W, H, NF = 640, 480, 1000
+    img = synth.stream(4, W, H, 1)[0]
+    ex = pkg.ORBextractor(NF, 1.2, 8, 20, 7, device=device, max_width=W, max_height=H, max_batch=1)
+    cap = ex.cap
+    fr = torch.from_numpy(img[None]).cuda()
+    k = torch.zeros((1, cap, 7), device="cuda"); d = torch.zeros((1, cap, 32), dtype=torch.uint8, device="cuda")
+    c = torch.zeros(1, dtype=torch.int32, device="cuda"); s = torch.zeros(1, dtype=torch.int32, device="cuda")
+    st = torch.cuda.Stream()
+
+    def dev_call():
+        ex.extract_batch_device(fr.data_ptr(), 1, W, H, fr.stride(1), fr.stride(0), k.data_ptr(), d.data_ptr(), c.data_ptr(), s.data_ptr(), st.cuda_stream)
+        st.synchronize()
+    for _ in range(20):
+        dev_call()
+    ts = []
+    for _ in range(reps):
+        t0 = time.perf_counter(); dev_call(); ts.append(time.perf_counter() - t0)
+    if int(s.item()) != 0:
+        raise RuntimeError("device status nonzero")
+    nk = int(c.item())
+    dev = np.sort(np.array(ts)) * 1e3
+    ex.set_profiling(True)
+    acc = np.zeros(4)
+    for _ in range(5):
+        dev_call(); acc += ex.stage_ms()
+    ex.set_profiling(False)
+    for _ in range(20):
+        ex(img)
+    ts = []
+    for _ in range(reps):
+        t0 = time.perf_counter(); kk, dd = ex(img); ts.append(time.perf_counter() - t0)
+    host = np.sort(np.array(ts)) * 1e3
+    q = lambda a, f: round(float(a[min(len(a) - 1, int(f * len(a)))]), 4)
+    return {"workload": "1 x 640x480 nFeatures=1000, extract (BASELINE configs[1] as written: a single frame)",
+            "keypoints": nk, "device_resident_ms": {"p50": q(dev, 0.5), "p90": q(dev, 0.9)},
+            "host_api_ms_pcie_inclusive": {"p50": q(host, 0.5), "p90": q(host, 0.9), "entry": "orbx_extract (one-frame handle: one HIP graph per call)"},
+            "frames_per_s_device_resident": round(1e3 / q(dev, 0.5), 1), "keypoints_per_s_device_resident": round(nk * 1e3 / q(dev, 0.5), 1),
+            "stage_ms": {n: round(float(v), 4) for n, v in zip(("pyramid", "fast", "quadtree", "describe"), acc / 5)}}
+
+
+def extra_tracking_loop(pkg, synth, nframes=40):
+    """BASELINE configs[4]: the Tracking-shaped per-frame loop (extract -> grid -> BoW -> SearchByBoW -> [PoseOptimization, EPnP RANSAC
+    relocalisation every 8th frame] -> SearchByProjection) on 1241x376 frames, nFeatures = 2000, host side in C++ through the C ABI
+    (tools/track/track_harness.cc, compiled here with g++; an ordinary child process).  Two runs: without and with the pose stages."""
+    import shutil
+    import subprocess
+    import tempfile
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from test_vocabulary import make_vocabulary
+    W, H, NF = 1241, 376, 2000
+    tmp = tempfile.mkdtemp(prefix="orbx_track_")
+    try:
+        exe = os.path.join(tmp, "track_harness")
+        libdir = os.path.dirname(pkg.LIB_PATH)
+        subprocess.run(["g++", "-O2", "-std=c++17", "-I", os.path.join(ROOT, "include"), os.path.join(ROOT, "tools", "track", "track_harness.cc"),
+                        "-L", libdir, "-lorbx", "-Wl,-rpath," + libdir, "-o", exe], check=True, capture_output=True, timeout=300)
+        # the inputs of tools/track/prep_inputs.py: the plain stream for the loop without pose, the three-depth scene for the pose
+        # stages, a synthetic 10^4-word vocabulary (k = 10, L = 4; FeatureVector nodes two levels up: 100 nodes)
+        synth.stream(5, W, H, nframes).tofile(os.path.join(tmp, "frames.raw"))
+        frames, layer = synth.stream_layers(5, W, H, nframes, shifts=(2, 4, 6))
+        frames.tofile(os.path.join(tmp, "frames_layers.raw")); layer.tofile(os.path.join(tmp, "layer.raw"))
+        make_vocabulary(os.path.join(tmp, "voc.txt"), 10, 4, seed=1)
+        tail = [str(W), str(H), str(nframes), os.path.join(tmp, "voc.txt"), str(NF), "2"]
+        base = [exe, os.path.join(tmp, "frames.raw")] + tail
+        base_pose = [exe, os.path.join(tmp, "frames_layers.raw")] + tail
+        out = {"workload": "%d x 1241x376 nFeatures=2000, one frame at a time: extract -> grid -> BoW -> SearchByBoW -> SearchByProjection, "
+                           "host side in C++ through the C ABI (BASELINE configs[4]); PCIe inclusive" % nframes}
+        r = subprocess.run(base, check=True, capture_output=True, text=True, timeout=300).stdout.strip().splitlines()
+        out["without_pose"] = json.loads(r[-1])
+        r = subprocess.run(base_pose + [os.path.join(tmp, "layer.raw"), "0.5", "2", "4", "6"], check=True, capture_output=True, text=True,
+                           timeout=300).stdout.strip().splitlines()
+        out["with_pose"] = json.loads(r[-1])
+        out["with_pose"]["pose"] = json.loads(r[-2])["pose"]
+        return out
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+
+
 def main():
     args = parse_args()
     if args.gpus < 1:
@@ -353,9 +474,18 @@ def main():
     local = local % max(ndev, 1)
     torch.cuda.set_device(local)
     dist = None
-    if world > 1:
+    # ORBX_BENCH_FORCE_COMM=1: take the communication branch with ONE rank too (process group of size 1, the per-step gather and a
+    # self-addressed boundary exchange on the same device-resident block): warms the RCCL path on a one-GPU box
+    force_comm = world == 1 and os.environ.get("ORBX_BENCH_FORCE_COMM", "0") == "1"
+    comm_on = world > 1 or force_comm
+    if comm_on:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if force_comm and "MASTER_PORT" not in os.environ:
+            import socket
+            with socket.socket() as sk:
+                sk.bind(("127.0.0.1", 0))
+                os.environ["MASTER_PORT"] = str(sk.getsockname()[1])
         if backend == "nccl":
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
         else:
@@ -382,7 +512,7 @@ def main():
     stream = torch.cuda.Stream()
     torch.cuda.set_stream(stream)
     assert stream.cuda_stream != 0
-    nslot = 2 if world > 1 else 1                     # two result blocks: the gather of step i overlaps step i+1
+    nslot = 2 if comm_on else 1                       # two result blocks: the gather of step i overlaps step i+1
     path = DevicePath(pkg, torch, shard, frames, W, H, B, NF, local, do_match, rank, world, nslot, stream)
     path.nown = nown
     ex, cap, layout = path.ex, path.cap, path.layout
@@ -390,14 +520,15 @@ def main():
         ex.set_subbatches(args.subbatches)
     on_gpu = backend == "nccl"
     gather_bufs = None
-    if world > 1 and rank == 0:
+    if comm_on and rank == 0:
         gather_bufs = [[torch.empty(layout.nbytes, dtype=torch.uint8, device="cuda" if on_gpu else "cpu") for _ in range(world)]
                        for _ in range(nslot)]
     # gloo rehearsal: communication goes through a host mirror of the block
-    mirror = [torch.empty(layout.nbytes, dtype=torch.uint8) for _ in range(nslot)] if (world > 1 and not on_gpu) else None
+    mirror = [torch.empty(layout.nbytes, dtype=torch.uint8) for _ in range(nslot)] if (comm_on and not on_gpu) else None
     pending = [None] * nslot
     sends = [[] for _ in range(nslot)]
     step_no = [0]
+    self_xchg = [None]
 
     def step():
         k = step_no[0] % nslot
@@ -416,7 +547,16 @@ def main():
                 kv[0].copy_(km[0]); dv[0].copy_(dm[0]); cv[0:1].copy_(cm[0:1])
             comm = {"comm_buf": mirror[k], "stage_out": stage_out, "stage_in": stage_in}
         sends[k] = path.step(k, comm=comm)
-        if world > 1:                      # RCCL over xGMI: the block goes back to rank 0, nothing else crosses GPUs
+        if force_comm and on_gpu and self_xchg[0] is not False:   # one rank: the boundary frame goes to itself (slot nown -> slot 0, which rank 0 never matches)
+            kv, dv, _, cv, _ = layout.views(path.bufs[k])
+            try:
+                sends[k] = dist.batch_isend_irecv([dist.P2POp(dist.isend, kv[nown], 0), dist.P2POp(dist.isend, dv[nown], 0),
+                                                   dist.P2POp(dist.isend, cv[nown:nown + 1], 0), dist.P2POp(dist.irecv, kv[0], 0),
+                                                   dist.P2POp(dist.irecv, dv[0], 0), dist.P2POp(dist.irecv, cv[0:1], 0)])
+                self_xchg[0] = True
+            except Exception as e:         # noqa: BLE001 -- RCCL may refuse a send to the sending rank: the gather below is still exercised
+                self_xchg[0] = False; self_xchg.append(str(e)[:200])
+        if comm_on:                        # RCCL over xGMI: the block goes back to rank 0, nothing else crosses GPUs
             if on_gpu:
                 pending[k] = shard.gather_flat(path.bufs[k], gather_bufs[k] if rank == 0 else None, async_op=True)
             else:
@@ -457,7 +597,7 @@ def main():
         torch.cuda.synchronize()
         if int(path.status.abs().sum().item()) != 0:
             raise SystemExit("device status nonzero after graph replay: %s" % path.status.tolist())
-    if world > 1:
+    if comm_on:
         dist.barrier()
     torch.cuda.synchronize()
     evs = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]   # per-step GPU times for the p50
@@ -468,11 +608,11 @@ def main():
         evs[i + 1].record(stream)
     drain()                      # every gather has landed on rank 0 inside the timed region
     torch.cuda.synchronize()
-    if world > 1:
+    if comm_on:
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
-    if world > 1:
+    if comm_on:
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if on_gpu else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -482,11 +622,11 @@ def main():
     nk_local = int(counts_v[1:nown + 1].sum().item())
     nm_local = int(nmatch_v[(2 if rank == 0 else 1):nown + 1].sum().item()) if do_match else 0
     tot = torch.tensor([nk_local, nm_local], dtype=torch.int64, device="cuda" if (world == 1 or on_gpu) else "cpu")
-    if world > 1:
+    if comm_on:
         dist.all_reduce(tot)
     nk_all, nm_all = int(tot[0].item()), int(tot[1].item())
     gathered_ok = None
-    if world > 1 and rank == 0:   # what rank 0 holds after the last gather is the whole stream's result
+    if comm_on and rank == 0:     # what rank 0 holds after the last gather is the whole stream's result
         last = (step_no[0] - 1) % nslot
         gk = sum(int(layout.views(gather_bufs[last][r])[3][1:ranges[r][1] - ranges[r][0] + 1].sum().item()) for r in range(world))
         gathered_ok = gk == nk_all
@@ -525,10 +665,14 @@ def main():
         nunits = npairs if dom == "match" else nown
         achieved = ab[dom] * nunits / (stage[dom] * 1e-3) / 1e9
         traffic = None
+        traffic_all = None
         tf = os.path.join(ROOT, "profiles", "traffic.json")
         if os.path.exists(tf) and (W, H, NF, nown) == (640, 480, 1000, 64):   # the PMC passes were taken on this workload
             try:
-                traffic = json.load(open(tf)).get(dom)
+                tj = json.load(open(tf))
+                traffic = tj.get(dom)
+                if all(k in tj for k in ("pyramid", "fast", "quadtree", "describe", "match")):
+                    traffic_all = sum(int(tj[k]) for k in ("pyramid", "fast", "quadtree", "describe") + (("match",) if do_match else ()))
             except Exception:
                 traffic = None
         # the other ceiling SURVEY.md 8(d) asks for: a device-to-device copy measured in this run (bytes read + written)
@@ -550,7 +694,11 @@ def main():
                 "measured_copy_GBps": round(copy_gbps, 1), "frac_of_measured_copy": round(achieved / copy_gbps, 5),
                 "stage_ms": {k: round(float(v), 4) for k, v in stage.items()},
                 "whole_path_algorithmic_GBps": round(sum(ab[k] for k in ("pyramid", "fast", "describe")) * total
-                                                     / (elapsed / args.steps) / 1e9, 2)}
+                                                     / (elapsed / args.steps) / 1e9, 2),
+                # measured: the counter bytes of every kernel of a step (profiles/traffic.json: FETCH_SIZE / WRITE_SIZE passes of this
+                # command, corrected as MI355X_MICROARCH.md prescribes) over the step time of THIS run
+                "whole_path_measured_bytes_per_step": traffic_all,
+                "whole_path_measured_GBps": round(traffic_all / (elapsed / args.steps) / 1e9, 2) if traffic_all else None}
 
     # ---- extras (N = 1 only; reported beside the contract's line, never as `value`) ----
     pipelined = host_api = extra = cpu = None
@@ -568,11 +716,16 @@ def main():
                 host_api = host_api_pass(pkg, frames_np, W, H, NF, local)
             except Exception as e:
                 host_api = {"error": str(e)[:200]}
-        if not args.no_extra_configs:
-            try:
-                extra = [extra_config3(pkg, torch, shard, synth, local)]
-            except Exception as e:
-                extra = [{"error": str(e)[:200]}]
+        if not args.no_extra_configs:     # the other BASELINE configs, so that the driver's run observes them (never `value`)
+            extra = []
+            for fn in (lambda: extra_single_frame(pkg, torch, synth, local),                  # configs[1] as written
+                       lambda: extra_config3(pkg, torch, shard, synth, local),                # configs[2]
+                       lambda: extra_tracking_loop(pkg, synth),                               # configs[4]
+                       lambda: extra_survey_stream(pkg, torch, shard, synth, local)):         # the headline step at a realistic corner density
+                try:
+                    extra.append(fn())
+                except Exception as e:             # noqa: BLE001 -- a side measurement must never cost the contract line
+                    extra.append({"error": str(e)[:300]})
         if not args.no_cpu_baseline:
             cpu = cpu_baseline(frames_np, NF, args.cpu_budget)
 
@@ -611,8 +764,16 @@ def main():
         }
         if gathered_ok is not None:
             out["gathered_on_rank0"] = gathered_ok
+        if force_comm:
+            kv, dv, _, cv, _ = layout.views(path.bufs[(step_no[0] - 1) % nslot])
+            out["forced_comm"] = {"backend": backend, "world_size": 1,
+                                  "self_exchange": "done" if self_xchg[0] else ("refused: " + (self_xchg[1] if len(self_xchg) > 1 else "not attempted")),
+                                  "self_exchange_ok": bool(self_xchg[0] and on_gpu and int(cv[0].item()) == int(cv[nown].item()) and bool((dv[0] == dv[nown]).all().item())
+                                                           and bool((kv[0].view(torch.int32) == kv[nown].view(torch.int32)).all().item())),   # bit patterns: class_id = -1 reads as NaN through the float view
+                                  "note": "process group of one rank: per step one batch_isend_irecv of the boundary frame to itself and one "
+                                          "asynchronous gather of the flat block, both on the device-resident block the N-rank run uses"}
         print(json.dumps(out))
-    if world > 1:
+    if comm_on:
         dist.barrier()
         dist.destroy_process_group()
 

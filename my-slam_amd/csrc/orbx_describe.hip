@@ -6,7 +6,10 @@
 #include "orb_pattern_data.h"
 #include <algorithm>
 #include <math.h>
-#define DW_RAW_STRIDE_H 48   // = DW_RAW_STRIDE below (host-side table builder)
+#ifndef DESC_RAW_STRIDE
+#define DESC_RAW_STRIDE 44
+#endif
+#define DW_RAW_STRIDE_H DESC_RAW_STRIDE   // = DW_RAW_STRIDE below (host-side table builder)
 #define DESC_R_H 18          // = DESC_R
 
 __constant__ int c_gauss[7];
@@ -184,13 +187,14 @@ extern "C" int orbx_debug_sincos(const float *h_theta, float *h_cos, float *h_si
 }
 
 // One wave per keypoint, four independent waves per workgroup (no workgroup barrier).  LDS per wave (all three in ONE buffer, below):
-//   raw  44 x 48 B   the 43x43 tile around the keypoint, column 0 at byte 0 (re-aligned at load time)
+//   raw  44 x 44 B   the 43x43 tile around the keypoint, column 0 at byte 0 (re-aligned at load time); 11 dwords per row: the 5 x 11
+//                    lanes of a tile-store pass and the (row pair, column group) tasks of the row pass fall on distinct banks
 //   P    22 x 160 B  row-blurred values, two vertically adjacent rows packed per dword (u16 | u16 << 16)
 //   bl   37 x 40 B   blurred 37x37
 // Row pass: 4 outputs from 3 dword reads, v_dot4_u32_u8 against shifted tap constants (taps are u8).
 // Column pass: the vertical pairs make every output 4 x v_dot2_u32_u16; exact integer sums, one
 // rounding at the end -- identical to row-then-column on u8 -> int32 -> u8 (OpenCV's fixed-point path).
-#define DW_RAW_STRIDE 48
+#define DW_RAW_STRIDE DESC_RAW_STRIDE
 #define DW_RAW_ROWS 44
 #define DW_P_STRIDE 40      // dwords per row pair
 #define DW_P_ROWS 22
@@ -218,6 +222,7 @@ __device__ __forceinline__ gptr_u8 scalar_ptr(const uint8_t *p)
     return (gptr_u8)(((uint64_t)hi << 32) | lo);
 }
 typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+typedef u32x2 __attribute__((may_alias)) u32x2_ma;
 typedef u32x2 __attribute__((aligned(4))) U2a4;   // two dwords at a 4-byte aligned address (global_load_dwordx2)
 
 // sum over the 64 lanes in six DPP additions (quad swaps, half-row and row mirrors, row broadcasts); every lane of the
@@ -233,10 +238,16 @@ __device__ __forceinline__ int wave_sum_dpp(int v)
     return __builtin_amdgcn_readlane(v, 63);
 }
 
+// Between two passes over the wave's LDS buffer.  The hardware needs nothing (a wave's LDS instructions execute in order); the
+// COMPILER must not move an access across: the wavefront-scope fences alone did not stop it from hoisting the column pass's
+// first loads above the row pass's last stores once the two used types that type-based alias analysis tells apart (round 3), so
+// an empty asm with a memory clobber stands next to them.
 #define DSYNC()                                                \
     do {                                                       \
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); \
+        asm volatile("" ::: "memory");                         \
         __builtin_amdgcn_wave_barrier();                       \
+        asm volatile("" ::: "memory");                         \
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); \
     } while (0)
 
@@ -402,7 +413,14 @@ __global__ __launch_bounds__(256, 8) void k_describe(
             // (row a | row b << 16), every sum <= 65535: one byte permute per output
             o[0] = __builtin_amdgcn_perm(rb0, ra0, 0x05040100u); o[1] = __builtin_amdgcn_perm(rb1, ra1, 0x05040100u);
             o[2] = __builtin_amdgcn_perm(rb2, ra2, 0x05040100u); o[3] = __builtin_amdgcn_perm(rb3, ra3, 0x05040100u);
+            // one ds_write_b128 (the P offset is a multiple of four dwords and the buffer is 16-byte aligned; without the promise the
+            // compiler splits the store into two ds_write2_b32, whose four dword stores at a 16-byte lane pitch are 4-way bank
+            // conflicts: 120 LDS cycles per keypoint instead of 39, tools/lds_model_describe.py)
+#ifndef DESC_NO_B128
+            *reinterpret_cast<uint4 *>(__builtin_assume_aligned(&reinterpret_cast<uint32_t *>(S.buf)[te >> 16], 16)) = make_uint4(o[0], o[1], o[2], o[3]);
+#else
             *reinterpret_cast<uint4 *>(&reinterpret_cast<uint32_t *>(S.buf)[te >> 16]) = make_uint4(o[0], o[1], o[2], o[3]);
+#endif
         }
     }
     DSYNC();
@@ -428,9 +446,23 @@ __global__ __launch_bounds__(256, 8) void k_describe(
                 const uint32_t *pin = &reinterpret_cast<const uint32_t *>(S.buf)[te & 1023u];
                 uint8_t *pout = &bl[(te >> 10) & 2047u];
                 typedef unsigned short us2 __attribute__((ext_vector_type(2)));
+                // volatile: four ds_read_b64 (two lane groups of 32, banks mod 64: 2 LDS cycles each when conflict-free).  Left alone the
+                // compiler pairs them into ds_read2_b64, which is serviced as 2 x 4 groups of 16 lanes on 32 banks: 148 instead of 76
+                // LDS cycles per keypoint for this pass (tools/lds_model_describe.py).  The LDS address space is spelled out (a volatile
+                // access through a generic pointer would be a flat load) and the type may alias anything.
+                // (w stays a HIP uint2 -- real members: __builtin_bit_cast of an ext-vector ELEMENT, `bit_cast<us2>(v.y)`, read the first
+                // four bytes of the whole vector with this compiler, i.e. v.x)
                 uint2 w[4];
+#ifndef DESC_NO_B64
+#pragma unroll
+                for (int j = 0; j < 4; j++) {
+                    const u32x2 t_ = *(const volatile __attribute__((address_space(3))) u32x2_ma *)(pin + j * DW_P_STRIDE);
+                    w[j].x = t_.x; w[j].y = t_.y;
+                }
+#else
 #pragma unroll
                 for (int j = 0; j < 4; j++) w[j] = *reinterpret_cast<const uint2 *>(pin + j * DW_P_STRIDE);
+#endif
 #define D2(A, K, ACC) __builtin_amdgcn_udot2(__builtin_bit_cast(us2, (A)), __builtin_bit_cast(us2, (uint32_t)(K)), (ACC), false)
                 // the rounding constant rides in the accumulator: every sum below is (exact sum + 32768) <= 0x01017FFF
                 const uint32_t e0 = D2(w[0].x, K01, D2(w[1].x, K23, D2(w[2].x, K45, D2(w[3].x, K6_, 32768u))));

@@ -67,11 +67,35 @@ def texture(seed, W, H, block_sizes=(7, 13, 29, 61), rect_density=0.004):
     return img
 
 
-def stream(seed, W, H, nframes, step=(2, 1), noise_seed0=100, noise=2, first=0, count=None):
+def texture_survey(seed, W, H):
+    """SURVEY.md 8(d)'s texture as written: 16 x 16-px blocks of uniform-random gray in [16, 240], overlaid with 0.002*W*H filled
+    axis-aligned rectangles of edge 8..64 px and random gray, then ONE 3 x 3 box blur.  A realistic corner density (the default
+    texture() above is several times denser on purpose): bench.py reports it as the second stream beside the headline one."""
+    bw, bh = (W + 15) // 16, (H + 15) // 16
+    r = splitmix64(seed * 1000 + 77, bw * bh)
+    b = (np.uint64(16) + r % np.uint64(225)).astype(np.uint8).reshape(bh, bw)
+    img = np.kron(b, np.ones((16, 16), dtype=np.uint8))[:H, :W].copy()
+    nrect = int(round(0.002 * W * H))
+    rr = splitmix64(seed ^ 0x5A5A5A5A, nrect * 5).reshape(nrect, 5)
+    for k in range(nrect):
+        rw = 8 + int(rr[k, 0] % np.uint64(57))
+        rh = 8 + int(rr[k, 1] % np.uint64(57))
+        x0 = int(rr[k, 2] % np.uint64(max(W - 1, 1)))
+        y0 = int(rr[k, 3] % np.uint64(max(H - 1, 1)))
+        img[y0:y0 + rh, x0:x0 + rw] = int(np.uint64(16) + rr[k, 4] % np.uint64(225))
+    return _box3(img)
+
+
+def stream_survey(seed, W, H, nframes, step=(2, 1), noise_seed0=100, noise=2, first=0, count=None):
+    """stream() on texture_survey(): SURVEY.md 8(d) C4 as written (the canvas shifted by (2k, k) px, noise seed 100 + k)."""
+    return stream(seed, W, H, nframes, step, noise_seed0, noise, first, count, canvas_fn=texture_survey)
+
+
+def stream(seed, W, H, nframes, step=(2, 1), noise_seed0=100, noise=2, first=0, count=None, canvas_fn=None):
     """nframes x H x W uint8: canvas T(seed) cropped at offset k*step plus +-noise gray.
     first/count: only frames [first, first+count) of that nframes-long stream (a rank's shard of it)."""
     pad_x, pad_y = step[0] * (nframes - 1), step[1] * (nframes - 1)
-    canvas = texture(seed, W + pad_x, H + pad_y)
+    canvas = (canvas_fn or texture)(seed, W + pad_x, H + pad_y)
     count = nframes - first if count is None else count
     out = np.empty((count, H, W), dtype=np.uint8)
     for j in range(count):

@@ -37,3 +37,17 @@ def test_two_ranks_equal_one_rank():
         assert r["keypoints_per_frame"] == one["keypoints_per_frame"]        # the same 8 frames of the same stream
         assert r["matches_per_step"] == one["matches_per_step"]              # including the pair that straddles the ranks
     assert one["roofline"]["frac"] > 0 and one["value"] > 0
+
+
+def test_rccl_path_on_one_gpu():
+    """The communication branch with ONE rank on the box's GPU, backend "nccl" (= RCCL), in a fresh process: the process group
+    initialises with device_id, dist.gather takes the uint8 flat block asynchronously every step and rank 0 ends up holding the
+    stream's result; the boundary frame is sent to the rank itself through batch_isend_irecv on the same views the N-rank run
+    uses.  What an 8-GPU run adds is more ranks, not other calls."""
+    r = _run(["--gpus", "1", "--batch", "8"], ORBX_BENCH_FORCE_COMM="1")
+    one = _run(["--gpus", "1", "--batch", "8"])
+    assert r["gathered_on_rank0"] is True
+    fc = r["forced_comm"]
+    assert fc["backend"] == "nccl" and fc["world_size"] == 1
+    assert fc["self_exchange_ok"], fc            # RCCL 2.26 accepts a send to the sending rank inside one group call
+    assert r["keypoints_per_frame"] == one["keypoints_per_frame"] and r["matches_per_step"] == one["matches_per_step"]
