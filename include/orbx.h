@@ -105,6 +105,16 @@ int orbx_extract_batch(orbx_extractor *h, const uint8_t *images, int nframes, in
                        orbx_keypoint *keypoints, uint8_t *descriptors, int cap, int *counts);
 
 /*
+ * The batched-frames mode sharded over several handles, normally one per GPU of the node (BASELINE north_star):
+ * one process, one host thread per handle.  Handle i takes the i-th contiguous block of the batch (sizes differ by at most one)
+ * and needs max_batch >= that block; outputs as for orbx_extract_batch, at the frames' own positions, so the result does not
+ * depend on the split.  Frames are independent: there is no collective on this path.
+ */
+int orbx_extract_batch_multi(orbx_extractor *const *handles, int nhandles, const uint8_t *images, int nframes, int width,
+                             int height, int row_stride, size_t frame_stride, orbx_keypoint *keypoints,
+                             uint8_t *descriptors, int cap, int *counts);
+
+/*
  * Device-resident batch: all pointers are HIP device pointers on the handle's device; the work is
  * enqueued on `hip_stream` (a hipStream_t, NULL = the handle's own stream) and NOT synchronised.
  * d_status[nframes] receives an orbx_status per frame.  The input must stay valid until the stream

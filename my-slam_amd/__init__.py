@@ -80,6 +80,8 @@ def lib():
     L.orbx_extract_batch_device.argtypes = [vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_size_t, vp, vp, C.c_int, vp, vp, vp]
     L.orbx_level_size.argtypes = [vp, C.c_int, ip, ip]
     L.orbx_download_level.argtypes = [vp, C.c_int, C.c_int, vp, C.c_int, C.c_int]
+    L.orbx_extract_batch_multi.argtypes = [vp, C.c_int, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_size_t, vp, vp, C.c_int, vp]
+    L.orbx_extract_batch_multi.restype = C.c_int
     L.orbx_download_pyramid.argtypes = [vp, C.c_int, vp, vp, C.c_int]
     L.orbx_download_pyramid.restype = C.c_int
     L.orbx_download_candidates.argtypes = [vp, C.c_int, C.c_int, vp, C.c_int]
@@ -395,6 +397,19 @@ class ORBextractor:
         if n < 0:
             _chk(n)
         return a[:n].copy()
+
+
+def extract_batch_multi(extractors, images):
+    """orbx_extract_batch_multi: one batch of host frames sharded over several ORBextractor handles (one per GPU; one host thread
+    each).  Returns (kps [B, cap], desc [B, cap, 32], counts [B]) like ORBextractor.extract_batch_raw."""
+    images = np.ascontiguousarray(images, dtype=np.uint8)
+    B, H, W = images.shape
+    cap = max(e.cap for e in extractors)
+    kps = np.zeros((B, cap), KP_DTYPE); desc = np.zeros((B, cap, 32), np.uint8); counts = np.zeros(B, np.int32)
+    hs = (C.c_void_p * len(extractors))(*[e.h for e in extractors])
+    _chk(lib().orbx_extract_batch_multi(hs, len(extractors), _p(images), B, W, H, images.strides[1], images.strides[0],
+                                        _p(kps), _p(desc), cap, _p(counts)))
+    return kps, desc, counts
 
 
 def ComputeStereoMatches(left, right, kl, dl, kr, dr, mb, mbf):

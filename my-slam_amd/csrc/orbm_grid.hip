@@ -471,7 +471,11 @@ int orbm_area_pairs(orbm_matcher *m, const float *x, const float *y, const float
     int32_t *soff = (int32_t *)orbm_stage_in(m, off.data(), ((size_t)nq + 1) * 4);      // place holder, filled after the counts are known
     if (!(sx && sy && sr && smn && smx && sq && st && soff)) {
         idx.assign((size_t)std::max<long long>(std::min<long long>(m->max_pairs, (long long)nq * n_train), 1), 0);
-        const int total = orbm_features_in_area(m, x, y, r, mn, mx, nq, off.data(), idx.data(), (int)idx.size());
+        int total = orbm_features_in_area(m, x, y, r, mn, mx, nq, off.data(), idx.data(), (int)idx.size());
+        if (total == ORBX_E_CAPACITY) {       // more candidates than the handle was created for: every window can hold at most n_train
+            idx.assign((size_t)std::max<long long>(std::min<long long>((long long)nq * n_train, INT_MAX), 1), 0);
+            total = orbm_features_in_area(m, x, y, r, mn, mx, nq, off.data(), idx.data(), (int)idx.size());
+        }
         if (total < 0) return total;
         idx.resize((size_t)std::max(total, 1));
         dist.assign((size_t)std::max(total, 1), 0);

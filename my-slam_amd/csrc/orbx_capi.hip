@@ -1037,6 +1037,47 @@ extern "C" int orbx_level_size(const orbx_extractor *h, int level, int *width, i
     return ORBX_OK;
 }
 
+// ---- the batched-frames mode sharded over several handles (BASELINE north_star: "a batched-frames mode shards
+// independent frames across the GPUs of one node") behind the C ABI: ONE process, one host thread and one set of streams per
+// handle.  Handle i (normally one per device; several on one device also work) takes the i-th contiguous block of the batch --
+// the split of my-slam_amd/shard.py's shard_range, sizes differ by at most one -- and runs orbx_extract_batch on it; every block's
+// outputs land in the caller's flat arrays at its frames' positions, so the result is the one-handle result whatever the split.
+// No collective: the frames are independent and the outputs are host arrays.  (RCCL carries only the device-resident gather of
+// bench.py's N-rank mode, where results stay in HBM.) ----
+extern "C" int orbx_extract_batch_multi(orbx_extractor *const *handles, int nhandles, const uint8_t *images, int nframes, int width,
+                                        int height, int row_stride, size_t frame_stride, orbx_keypoint *keypoints,
+                                        uint8_t *descriptors, int cap, int *counts)
+{
+    if (!handles || nhandles < 1) return fail(ORBX_E_INVALID, "no handles");
+    for (int i = 0; i < nhandles; i++) {
+        if (!handles[i]) return fail(ORBX_E_INVALID, "handle %d is NULL", i);
+        for (int j = 0; j < i; j++)
+            if (handles[j] == handles[i]) return fail(ORBX_E_INVALID, "handle %d is handle %d again: a handle is not re-entrant", i, j);
+    }
+    if (!counts) return fail(ORBX_E_INVALID, "counts is NULL");
+    for (int k = 0; k < std::max(nframes, 0); k++) counts[k] = 0;
+    if (!images || width <= 0 || height <= 0 || nframes <= 0) return ORBX_OK;
+    if (!keypoints || !descriptors) return fail(ORBX_E_INVALID, "NULL output buffer");
+    const int nh = std::min(nhandles, nframes);
+    std::vector<int> lo(nh + 1);
+    for (int i = 0; i <= nh; i++) lo[i] = i * (nframes / nh) + std::min(i, nframes % nh);
+    std::vector<int> rc(nh, ORBX_OK);
+    std::vector<std::string> msg(nh);
+    auto run = [&](int i) {
+        const int a = lo[i], n = lo[i + 1] - a;
+        rc[i] = orbx_extract_batch(handles[i], images + (size_t)a * frame_stride, n, width, height, row_stride, frame_stride,
+                                   keypoints + (size_t)a * cap, descriptors + (size_t)a * cap * 32, cap, counts + a);
+        if (rc[i] != ORBX_OK) msg[i] = orbx_last_error();          // the error text is thread-local: carry it over
+    };
+    std::vector<std::thread> th;
+    for (int i = 1; i < nh; i++) th.emplace_back(run, i);
+    run(0);
+    for (auto &t : th) t.join();
+    for (int i = 0; i < nh; i++)
+        if (rc[i] != ORBX_OK) return fail(rc[i], "block %d (frames %d..%d, device %d): %s", i, lo[i], lo[i + 1] - 1, handles[i]->device, msg[i].c_str());
+    return ORBX_OK;
+}
+
 static inline int reflect101_host(int p, int len)
 {
     if (len == 1) return 0;

@@ -335,3 +335,27 @@ def test_extract_begin_end_pipelined(orbx, synth):
     ex[1].extract_begin(None)                   # the reference's silent return on an empty image
     kp, de = ex[1].extract_end()
     assert len(kp) == 0 and de.shape == (0, 32)
+
+
+def test_batch_sharded_over_handles(orbx, synth):
+    """orbx_extract_batch_multi: one batch over several handles (one per GPU on a multi-GPU node; here three handles on the box's one
+    GPU, and as many devices as the box shows), one host thread each, contiguous blocks -- the result is the one-handle result
+    whatever the split, including a split with more handles than frames."""
+    import torch
+    W, H, B = 640, 480, 11
+    frames = synth.stream(4, W, H, B)
+    one = orbx.ORBextractor(1000, max_width=W, max_height=H, max_batch=B)
+    k1, d1, c1 = [a.copy() for a in one.extract_batch_raw(frames)]
+    ndev = max(1, torch.cuda.device_count())
+    hs = [orbx.ORBextractor(1000, max_width=W, max_height=H, max_batch=4, device=i % ndev) for i in range(3)]
+    k3, d3, c3 = orbx.extract_batch_multi(hs, frames)
+    assert np.array_equal(c1, c3) and c3.min() > 900
+    for f in range(B):
+        n = int(c1[f])
+        assert k1[f, :n].tobytes() == k3[f, :n].tobytes() and np.array_equal(d1[f, :n], d3[f, :n])
+    k2, d2, c2 = orbx.extract_batch_multi(hs, frames[:2])                      # fewer frames than handles
+    assert np.array_equal(c2, c1[:2]) and k2[1, :c2[1]].tobytes() == k1[1, :c1[1]].tobytes()
+    with pytest.raises(orbx.OrbxError):                                        # a block larger than its handle's max_batch
+        orbx.extract_batch_multi(hs[:2], frames)
+    with pytest.raises(orbx.OrbxError):
+        orbx.extract_batch_multi([hs[0], hs[0]], frames[:4])

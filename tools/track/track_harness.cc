@@ -33,6 +33,16 @@
 static double now_ms() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 #define CHK(e) do { int rc_ = (e); if (rc_ < 0) { fprintf(stderr, "%s failed: %d (%s | %s | %s)\n", #e, rc_, orbx_last_error(), orbm_last_error(), orbv_last_error()); return 2; } } while (0)
 
+// ORBX_TRACK_DUMP=<dir>: every frame's inputs and match tables are written to <dir>/frame_<k>.bin so that a test can run the
+// oracle on the SAME extracted features and poses and compare the tables exactly (tests/test_track_harness_gpu.py)
+struct Dump {
+    FILE *f = nullptr;
+    bool open(const char *dir, int k) { char p[1024]; snprintf(p, sizeof p, "%s/frame_%03d.bin", dir, k); f = fopen(p, "wb"); return f != nullptr; }
+    template <class T> void put(const T *p, size_t n) { if (f && n) fwrite(p, sizeof(T), n, f); }
+    void i32(int32_t v) { put(&v, 1); }
+    void close() { if (f) fclose(f); f = nullptr; }
+};
+
 struct FrameData {
     std::vector<orbx_keypoint> kps;
     std::vector<uint8_t> desc;
@@ -46,6 +56,7 @@ int main(int argc, char **argv)
     const char *fpath = argv[1]; const int W = atoi(argv[2]), H = atoi(argv[3]), K = atoi(argv[4]);
     const char *vpath = argv[5]; const int NF = atoi(argv[6]); const int levelsup = argc > 7 ? atoi(argv[7]) : 2;
     const bool pose = argc > 12;
+    const char *dump_dir = getenv("ORBX_TRACK_DUMP");
     const float fx = 718.856f, fy = 718.856f, cx = 607.1928f, cy = 185.2157f;      // Examples/Monocular/KITTI00-02.yaml
     std::vector<uint8_t> layer;
     double base = 0, depth[3] = {0, 0, 0};
@@ -81,7 +92,8 @@ int main(int argc, char **argv)
     float Tprev[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};       // frame 0 = world
     std::vector<float> obs(2 * cap), is2(cap), xw(3 * cap), s2(cap);
     std::vector<uint8_t> outl(cap), inl(cap);
-    double max_err = 0, max_reloc_err = 0;
+    double max_err = 0, max_reloc_err = 0, max_axis[3] = {0, 0, 0}, ck_err[8];
+    int ck_frame[8], n_ck = 0;
     float Tlast[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};
     std::vector<float> xw_all(3 * cap);
     std::vector<uint8_t> ones(cap, 1);
@@ -111,6 +123,16 @@ int main(int argc, char **argv)
                                    cur.fv_off.data(), cur.fv_idx.data(), cur.fv_n, 0.7f, 1, match_f.data(), &nm));
             nm_bow += nm;
             const double t4 = now_ms();
+            Dump dump;
+            if (dump_dir && dump.open(dump_dir, k)) {
+                const int32_t hdr[8] = {prev.n, cur.n, prev.fv_n, prev.fv_off[prev.fv_n], cur.fv_n, cur.fv_off[cur.fv_n], pose ? 1 : 0, nm};
+                dump.put(hdr, 8);
+                dump.put(prev.kps.data(), (size_t)prev.n); dump.put(prev.desc.data(), (size_t)prev.n * 32);
+                dump.put(cur.kps.data(), (size_t)cur.n); dump.put(cur.desc.data(), (size_t)cur.n * 32);
+                dump.put(prev.fv_node.data(), (size_t)prev.fv_n); dump.put(prev.fv_off.data(), (size_t)prev.fv_n + 1); dump.put(prev.fv_idx.data(), (size_t)prev.fv_off[prev.fv_n]);
+                dump.put(cur.fv_node.data(), (size_t)cur.fv_n); dump.put(cur.fv_off.data(), (size_t)cur.fv_n + 1); dump.put(cur.fv_idx.data(), (size_t)cur.fv_off[cur.fv_n]);
+                dump.put(match_f.data(), (size_t)cur.n);
+            }
             if (pose) {
                 // MapPoints of the previous frame: Xc = K^-1 (u, v, 1) * depth(layer), Xw = Rprev^T (Xc - tprev)
                 int nc = 0;
@@ -137,6 +159,11 @@ int main(int argc, char **argv)
                 if (k >= 5) t_pose.push_back(tp1 - tp0);
                 const double err = std::fabs(T[3] + k * base) + std::fabs(T[7]) + std::fabs(T[11]);
                 max_err = std::max(max_err, err / base);
+                // per axis, and at checkpoints: the chain is dead reckoning (every frame's MapPoints are rebuilt through the previous
+                // ESTIMATE), so the error is a random walk; z is the weakly observed axis of this fronto-parallel scene
+                max_axis[0] = std::max(max_axis[0], std::fabs(T[3] + k * base) / base); max_axis[1] = std::max(max_axis[1], std::fabs((double)T[7]) / base);
+                max_axis[2] = std::max(max_axis[2], std::fabs((double)T[11]) / base);
+                if (k % 8 == 0 && n_ck < 8) { ck_frame[n_ck] = k; ck_err[n_ck] = err / base; n_ck++; }
                 if (k % 8 == 0) {            // relocalisation: no prior, EPnP RANSAC then pose optimisation on its inliers' pose
                     const double tr0 = now_ms();
                     orbp_pnp *ps = nullptr;
@@ -209,6 +236,7 @@ int main(int argc, char **argv)
                                                    fx, fy, cx, cy, 0.f, 0.f, bounds, sfac, 8, cur.kps.data(), cur.desc.data(), nullptr, cur.n,
                                                    15.0f, 1, 1, cur_obs.data(), cur_match.data(), &nmp));
                 nm_proj += nmp;
+                if (dump.f) { dump.put(Tprev, 16); dump.put(Tlast, 16); dump.put(xw_all.data(), (size_t)3 * prev.n); dump.put(cur_match.data(), (size_t)cur.n); dump.i32(nmp); }
             } else {
             for (int i = 0; i < prev.n; i++) {           // motion-model windows around the previous positions
                 const orbx_keypoint &p = prev.kps[i];
@@ -219,8 +247,11 @@ int main(int argc, char **argv)
                                        cur.desc.data(), nullptr, bi.data(), bd.data(), sd.data()));
             for (int i = 0; i < prev.n; i++) m12[i] = bd[i] <= ORBM_TH_HIGH ? bi[i] : -1;
             for (int i = 0; i < cur.n; i++) at[i] = cur.kps[i].angle;
-            nm_proj += orbm_rot_filter(aq.data(), at.data(), m12.data(), prev.n);
+            const int nrot = orbm_rot_filter(aq.data(), at.data(), m12.data(), prev.n);
+            nm_proj += nrot;
+            if (dump.f) { dump.put(qr.data(), (size_t)prev.n); dump.put(m12.data(), (size_t)prev.n); dump.i32(nrot); }
             }
+            dump.close();
             const double t5 = now_ms();
             if (k >= 5) {
                 const double d[5] = {t1 - t0, t2 - t1, t3 - t2, t4 - t3, t5 - t4b};
@@ -238,9 +269,12 @@ int main(int argc, char **argv)
         std::sort(t_pose.begin(), t_pose.end()); std::sort(t_reloc.begin(), t_reloc.end());
         printf("{\"pose\": {\"ms_median_pose_optimization\": %.3f, \"ms_median_relocalization\": %.3f, \"inliers_per_frame\": %.1f, "
                "\"max_translation_error_in_baselines\": %.4f, \"relocalizations\": \"%ld/%ld\", \"max_reloc_error_in_baselines\": %.4f, "
-               "\"reloc_search_by_projection_kf_matches\": %.1f}}\n",
+               "\"reloc_search_by_projection_kf_matches\": %.1f, \"max_error_per_axis_in_baselines\": [%.4f, %.4f, %.4f], \"error_at_frame\": {",
                t_pose.empty() ? 0 : t_pose[t_pose.size() / 2], t_reloc.empty() ? 0 : t_reloc[t_reloc.size() / 2],
-               (double)n_inl / std::max(K - 1, 1), max_err, n_reloc_ok, n_reloc, max_reloc_err, (double)n_reloc_add / std::max(n_reloc_ok, 1L));
+               (double)n_inl / std::max(K - 1, 1), max_err, n_reloc_ok, n_reloc, max_reloc_err, (double)n_reloc_add / std::max(n_reloc_ok, 1L),
+               max_axis[0], max_axis[1], max_axis[2]);
+        for (int i = 0; i < n_ck; i++) printf("%s\"%d\": %.4f", i ? ", " : "", ck_frame[i], ck_err[i]);
+        printf("}}}\n");
     }
     printf("{\"harness\": \"C++ through the C ABI\", \"shape\": \"%dx%d n=%d\", \"frames_timed\": %d, \"ms_per_frame_median\": %.3f, \"frames_per_s\": %.1f, "
            "\"ms_median\": {\"extract\": %.3f, \"grid\": %.3f, \"bow\": %.3f, \"search_by_bow\": %.3f, \"search_by_projection\": %.3f}, "
