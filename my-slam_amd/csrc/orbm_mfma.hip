@@ -28,7 +28,12 @@ typedef int v16i __attribute__((ext_vector_type(16)));
 #define MF_KEY_NONE ((256u << 22) | 0x3FFFFFu)
 #define MF_ACC_NONE (-(1 << 30))        // "no candidate yet"; a real acc is >= -(4096 * 256 + 4095)
 #define MF_ROW_NONE (-(1 << 29))        // start value of a row beyond the train count: stays below every real acc
+#ifndef MF_QB
 #define MF_QB 2                         // query blocks (32 queries each) per wave
+#endif
+#ifndef MF_OCC
+#define MF_OCC 3                        // workgroups per CU the register budget is held to
+#endif
 #define MF_CHUNK 4096                   // train descriptors per index chunk (12 bits)
 
 // 16 descriptor bits -> the 16 operand bytes of one lane and k-step: -64 for a set bit, +64 for a clear one (both operands are
@@ -77,7 +82,9 @@ __device__ __forceinline__ void mf_fold(int &ba, int &sa, uint32_t &bk, uint32_t
 // up front spent 3.4 of its 8 us waiting, in lockstep with its neighbours: two rounds of that were 24 us).  Three workgroups
 // per CU (register budget): MFMAs of one wave run beside the selection VALU of another.  The 1-D grid is ordered pair-major and
 // dealt to the XCDs in contiguous eighths (placement only, as in k_fast_cells), so the workgroups of a pair share an L2.
+#ifndef MF_STG
 #define MF_STG 3
+#endif
 #ifdef MF_TRACE
 __device__ unsigned long long g_mf_trace[4 * 4096];
 extern "C" int orbm_debug_mf_trace(unsigned long long *out) { return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_mf_trace), sizeof(g_mf_trace)); }
@@ -85,7 +92,7 @@ extern "C" int orbm_debug_mf_trace(unsigned long long *out) { return (int)hipMem
 #else
 #define MF_STAMP(i) do { } while (0)
 #endif
-__global__ __launch_bounds__(256, 3) void k_best2_mfma(const uint8_t *__restrict__ q, const int32_t *__restrict__ nqv, int nq_fixed,
+__global__ __launch_bounds__(256, MF_OCC) void k_best2_mfma(const uint8_t *__restrict__ q, const int32_t *__restrict__ nqv, int nq_fixed,
                                                        const uint8_t *__restrict__ t, const int32_t *__restrict__ ntv, int nt_fixed,
                                                        long long qstride, long long tstride, int cap_q, int cap_t, int out_stride,
                                                        uint2 *__restrict__ part, int nbx, int S, int nbatch, int total)
@@ -236,7 +243,7 @@ int orbm_mfma_splits(int nq_cap, int nt_cap, int nbatch)
     // parts of the train range per frame pair: enough workgroups for three per CU (one round), a part not shorter than two stages
     const int ttiles = std::max((nt_cap + 31) >> 5, 1);
     const long long wgs = (long long)nbatch * ((((nq_cap + 31) >> 5) + 4 * MF_QB - 1) / (4 * MF_QB));
-    int S = (int)std::max<long long>((768 + wgs - 1) / std::max<long long>(wgs, 1), 1);
+    int S = (int)std::max<long long>((256 * MF_OCC + wgs - 1) / std::max<long long>(wgs, 1), 1);
     static const int forced = [] { const char *e = getenv("ORBM_MFMA_SPLITS"); return e ? std::max(atoi(e), 1) : 0; }();   // tuning switch, read once
     if (forced) S = forced;
     S = std::min(S, std::max(ttiles / (2 * MF_STG), 1));
