@@ -57,6 +57,11 @@ int main(int argc, char **argv)
     const char *vpath = argv[5]; const int NF = atoi(argv[6]); const int levelsup = argc > 7 ? atoi(argv[7]) : 2;
     const bool pose = argc > 12;
     const char *dump_dir = getenv("ORBX_TRACK_DUMP");
+    // The tiles of synth.stream_layers are fixed in IMAGE space: a corner made by the junction of two layers at a tile edge does not
+    // move at all from frame to frame, yet it is given the finite depth of its layer.  Such features pull every pose estimate
+    // towards "no motion" -- a bias, not noise: the chained error grows linearly along the direction of travel.  With a margin
+    // (in level-0 pixels per unit of the feature's scale) they are left out of the pose inputs and the drift shows its true size.
+    const float edge_margin = getenv("ORBX_TRACK_EDGE_MARGIN") ? (float)atof(getenv("ORBX_TRACK_EDGE_MARGIN")) : 0.f;
     const float fx = 718.856f, fy = 718.856f, cx = 607.1928f, cy = 185.2157f;      // Examples/Monocular/KITTI00-02.yaml
     std::vector<uint8_t> layer;
     double base = 0, depth[3] = {0, 0, 0};
@@ -140,6 +145,11 @@ int main(int argc, char **argv)
                     const int j = match_f[i];
                     if (j < 0) continue;
                     const orbx_keypoint &p = prev.kps[j], &c = cur.kps[i];
+                    if (edge_margin > 0) {      // ORBX_TRACK_EDGE_MARGIN: leave out features whose patch touches a tile edge of the synthetic scene
+                        const float m = edge_margin * sfac[p.octave];
+                        const float dx = fmodf(p.x, 96.f), dy = fmodf(p.y, 96.f);
+                        if (std::min(dx, 96.f - dx) < m || std::min(dy, 96.f - dy) < m) continue;
+                    }
                     const int px = std::min(std::max((int)lrintf(p.x), 0), W - 1), py = std::min(std::max((int)lrintf(p.y), 0), H - 1);
                     const double Z = depth[layer[(size_t)py * W + px]];
                     const double Xc[3] = {(p.x - cx) * Z / fx - Tprev[3], (p.y - cy) * Z / fy - Tprev[7], Z - Tprev[11]};
