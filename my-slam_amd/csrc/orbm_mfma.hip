@@ -238,10 +238,226 @@ __global__ __launch_bounds__(256, MF_OCC) void k_best2_mfma(const uint8_t *__res
     MF_STAMP(2);
 }
 
+// -------------------------------------------------------------------------------------------------
+// Software-pipelined form (round 3).  k_best2_mfma above issues a tile's 16 MFMAs back to back and then the 64 selection
+// instructions on their results: inside one wave the matrix pipe idles during the selection and the vector pipe during the MFMAs,
+// and three co-resident waves per SIMD did not interleave well enough to hide it (MFMA pipe ~30 % busy, 21.8 us at 63 x 1007 x 1007
+// against 6.7 us of matrix time; splits, occupancy, stage depth: no effect).  Here ONE wave per SIMD carries both
+// streams itself: the accumulators are double-buffered and the selection of tile j-1 is scheduled into the gaps between the MFMAs of
+// tile j (an MFMA occupies the SIMD's vector issue for 8 of its 32 cycles: ~5 single-issue instructions fit per gap,
+// MI355X_MICROARCH.md), placed with __builtin_amdgcn_sched_group_barrier.  What that needs:
+//   * the selection as 3 instructions per TWO elements (v_max3_i32, v_med3_i32, v_max_i32) -- 48 per tile and wave instead of 64;
+//   * NO per-tile accumulator seed: the seed is the loop-invariant -(row inside the tile), and instead of re-basing 16 new values per
+//     tile the running (best, second) of a query are kept RELATIVE to the tile in hand (+32 per tile: 4 scalar-operand adds).
+//     acc = 4096 * (256 - 2 dist) + o = 8192 * (128 - dist) + o with o = (first row of the frame's tile) - (row of the element):
+//     o is in [-31, 0] for the tile in hand and grows by 32 per tile for older elements; with o + 31 < 8192 the distance field is
+//     never touched, so larger acc <=> smaller distance, then smaller row -- the reference's order (the rows of one query are all
+//     distinct).  The range is walked in chunks of 4096 rows, banked into (distance << 22 | row) keys at each chunk end.
+//   * one workgroup (4 waves x 2 query blocks = 256 queries) per CU and no train split when there are enough pairs: 63 pairs x 4
+//     workgroups = 252 for the 256 CUs.
+// Same operands, same partial format, same tie rules as above; tests/test_matcher_gpu.py runs both.
+// -------------------------------------------------------------------------------------------------
+#define SP_STG 4                          // tiles per LDS stage (even: the accumulator parity of a tile is then a compile-time fact)
+#define SP_LDS_BYTES (2 * SP_STG * 512 * 16 + 256 * 8)
+
+// second largest of {ba >= sa, x, y} and the largest, 3 instructions for two elements
+__device__ __forceinline__ void sp_select2(int &ba, int &sa, int x, int y)
+{
+    const int m = mf_med3i(ba, x, y);
+    ba = max(max(ba, x), y);
+    sa = max(sa, m);
+}
+// (best, second) in the frame whose tile starts at row fbase -> keys
+__device__ __forceinline__ void sp_fold(int &ba, int &sa, uint32_t &bk, uint32_t &sk, int fbase)
+{
+#pragma unroll
+    for (int k = 0; k < 2; k++) {
+        const int x = k == 0 ? ba : sa;
+        if (x > -(1 << 22)) {
+            const int w = x + 31;
+            const int dist = 128 - (w >> 13);                    // arithmetic shift: floor
+            const int o = (w & 8191) - 31;
+            const uint32_t key = ((uint32_t)dist << 22) | (uint32_t)(fbase - o);
+            sk = mf_med3u(bk, sk, key);
+            bk = min(bk, key);
+        }
+    }
+    ba = MF_ACC_NONE; sa = MF_ACC_NONE;
+}
+
+__global__ __launch_bounds__(256, 1) void k_best2_mfma_sp(const uint8_t *__restrict__ q, const int32_t *__restrict__ nqv, int nq_fixed,
+                                                          const uint8_t *__restrict__ t, const int32_t *__restrict__ ntv, int nt_fixed,
+                                                          long long qstride, long long tstride, int cap_q, int cap_t, int out_stride,
+                                                          uint2 *__restrict__ part, int nbx, int S, int nbatch, int total)
+{
+    extern __shared__ __attribute__((aligned(16))) uint4 sp_lds[];      // two stages of SP_STG tiles as operand bytes, then the 2 KiB table
+    uint2 *lut = reinterpret_cast<uint2 *>(sp_lds + 2 * SP_STG * 512);
+    const int lb = (int)(blockIdx.x & 7u) * (int)(gridDim.x >> 3) + (int)(blockIdx.x >> 3);
+    if (lb >= total) return;
+    const int b = lb / (nbx * S), rem = lb - b * (nbx * S), bz = rem / nbx, bx = rem - bz * nbx;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int qb0 = (bx * 4 + wave) * 2;
+    const uint8_t *Q = q + (long long)b * qstride, *T = t + (long long)b * tstride;
+    const int ttiles_cap = (cap_t + 31) >> 5, per = (ttiles_cap + S - 1) / S;
+    const int t0 = bz * per, t1c = min(ttiles_cap, t0 + per);
+    const int tr = tid & 31, ts = tid >> 5;
+    uint32_t tw[SP_STG];
+    auto load_stage = [&](int tt, int tend) {
+#pragma unroll
+        for (int j = 0; j < SP_STG; j++) {
+            const int row = (tt + j) * 32 + tr;
+            tw[j] = (tt + j < tend && row < cap_t) ? *reinterpret_cast<const uint32_t *>(T + (long long)row * 32 + 4 * ts) : 0u;
+        }
+    };
+    load_stage(t0, t1c);
+    const int qr = lane & 31, qh = lane >> 5;
+    uint4 qw[2][2];
+#pragma unroll
+    for (int u = 0; u < 2; u++) {
+        const int row = (qb0 + u) * 32 + qr;
+        qw[u][0] = qw[u][1] = make_uint4(0, 0, 0, 0);
+        if (row < cap_q) {
+            const uint4 *p = reinterpret_cast<const uint4 *>(Q + (long long)row * 32);
+            qw[u][0] = p[0]; qw[u][1] = p[1];
+        }
+    }
+    const int nq = nqv ? nqv[b] : nq_fixed, nt = ntv ? ntv[b] : nt_fixed;
+    const int qblocks = (nq + 31) >> 5;
+    if (bx * 8 >= qblocks) return;                                          // nothing for this workgroup (uniform)
+    const bool active = qb0 < qblocks;                                       // wave-uniform; idle waves still help staging
+    const int t1 = min((nt + 31) >> 5, t1c);
+    {
+        const uint4 e = mf_expand16((uint32_t)tid);
+        lut[tid] = make_uint2(e.x, e.y);
+    }
+    __syncthreads();
+    auto expand16 = [&](uint32_t bits) -> uint4 {
+        const uint2 a = lut[bits & 255u], b2 = lut[(bits >> 8) & 255u];
+        return make_uint4(a.x, a.y, b2.x, b2.y);
+    };
+    auto expand_stage = [&](int tt, int buf) {
+#pragma unroll
+        for (int j = 0; j < SP_STG; j++)
+            if (tt + j < t1) {
+                const bool valid = (tt + j) * 32 + tr < nt;
+                uint4 *L = sp_lds + (size_t)buf * (SP_STG * 512) + j * 512 + ts * 64 + tr;
+                L[0] = valid ? expand16(tw[j] & 0xFFFFu) : make_uint4(0, 0, 0, 0);
+                L[32] = valid ? expand16(tw[j] >> 16) : make_uint4(0, 0, 0, 0);
+            }
+    };
+    expand_stage(t0, 0);
+    v4i bq[2][8];
+#pragma unroll
+    for (int u = 0; u < 2; u++) {
+        const uint32_t w8[8] = {qw[u][0].x, qw[u][0].y, qw[u][0].z, qw[u][0].w, qw[u][1].x, qw[u][1].y, qw[u][1].z, qw[u][1].w};
+#pragma unroll
+        for (int s = 0; s < 8; s++) bq[u][s] = __builtin_bit_cast(v4i, expand16((w8[s] >> (16 * qh)) & 0xFFFFu));
+    }
+    __syncthreads();
+
+    const int h4 = 4 * (lane >> 5);
+    v16i init0, accE[2], accO[2];
+#pragma unroll
+    for (int r = 0; r < 16; r++) { init0[r] = -(h4 + (r & 3) + 8 * (r >> 2)); accO[0][r] = MF_ACC_NONE; accO[1][r] = MF_ACC_NONE; }
+    int ba[2] = {MF_ACC_NONE, MF_ACC_NONE}, sa[2] = {MF_ACC_NONE, MF_ACC_NONE};
+    uint32_t bk[2] = {MF_KEY_NONE, MF_KEY_NONE}, sk[2] = {MF_KEY_NONE, MF_KEY_NONE};
+    int fbase = t0 * 32, pbase = t0 * 32, chunk0 = t0 * 32;      // frame of (ba, sa); first row of the pending tile; first row of the chunk
+    int lastpar = 1;                                             // parity of the accumulator set that is pending (accO holds nothing real yet)
+
+    // one tile: its 16 MFMAs into CUR, the selection of the pending tile (PRV) in their gaps
+#define SP_STEP(CUR, PRV, BASE)                                                                                          \
+    do {                                                                                                                 \
+        if (pbase - chunk0 >= MF_CHUNK) {                      /* rare: > 4096 train rows */                             \
+            sp_fold(ba[0], sa[0], bk[0], sk[0], fbase); sp_fold(ba[1], sa[1], bk[1], sk[1], fbase);                      \
+            chunk0 = pbase;                                                                                              \
+        }                                                                                                                \
+        const int delta_ = pbase - fbase;                                                                                \
+        ba[0] += delta_; sa[0] += delta_; ba[1] += delta_; sa[1] += delta_;                                              \
+        fbase = pbase;                                                                                                   \
+        v16i ini_ = init0;                                                                                               \
+        if ((BASE) + 32 > nt) {                                /* last, partial tile: rows beyond the train count never win */ \
+            _Pragma("unroll") for (int r = 0; r < 16; r++)                                                               \
+                if ((BASE) + h4 + (r & 3) + 8 * (r >> 2) >= nt) ini_[r] = MF_ROW_NONE;                                   \
+        }                                                                                                                \
+        v4i a_[8];                                                                                                       \
+        _Pragma("unroll") for (int s = 0; s < 8; s++) a_[s] = __builtin_bit_cast(v4i, A_[s * 64 + lane]);                \
+        CUR[0] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a_[0], bq[0][0], ini_, 0, 0, 0);                                  \
+        CUR[1] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a_[0], bq[1][0], ini_, 0, 0, 0);                                  \
+        _Pragma("unroll") for (int s = 1; s < 8; s++) {                                                                  \
+            CUR[0] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a_[s], bq[0][s], CUR[0], 0, 0, 0);                            \
+            CUR[1] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a_[s], bq[1][s], CUR[1], 0, 0, 0);                            \
+        }                                                                                                                \
+        _Pragma("unroll") for (int r = 0; r < 16; r += 2) {                                                              \
+            sp_select2(ba[0], sa[0], PRV[0][r], PRV[0][r + 1]);                                                          \
+            sp_select2(ba[1], sa[1], PRV[1][r], PRV[1][r + 1]);                                                          \
+        }                                                                                                                \
+        _Pragma("unroll") for (int g = 0; g < 16; g++) {       /* MFMA, 3 vector instructions, MFMA, ... */              \
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                                           \
+            __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);                                                           \
+        }                                                                                                                \
+        pbase = (BASE);                                                                                                  \
+    } while (0)
+
+    int buf = 0;
+    for (int tt = t0; tt < t1; tt += SP_STG) {
+        const bool more = tt + SP_STG < t1;
+        if (more) load_stage(tt + SP_STG, t1);                  // in flight during this stage's MFMAs
+        if (active) {
+#pragma unroll
+            for (int j = 0; j < SP_STG; j++) {
+                if (tt + j >= t1) break;
+                const uint4 *A_ = sp_lds + (size_t)buf * (SP_STG * 512) + j * 512;
+                if ((j & 1) == 0) { SP_STEP(accE, accO, (tt + j) * 32); lastpar = 0; }
+                else { SP_STEP(accO, accE, (tt + j) * 32); lastpar = 1; }
+            }
+        }
+        if (more) {
+            expand_stage(tt + SP_STG, buf ^ 1);
+            __syncthreads();
+        }
+        buf ^= 1;
+    }
+#undef SP_STEP
+    if (!active) return;
+    {   // the pending tile, then the chunk
+        const int delta = pbase - fbase;
+        ba[0] += delta; sa[0] += delta; ba[1] += delta; sa[1] += delta;
+        fbase = pbase;
+#pragma unroll
+        for (int r = 0; r < 16; r += 2) {
+            if (lastpar == 0) { sp_select2(ba[0], sa[0], accE[0][r], accE[0][r + 1]); sp_select2(ba[1], sa[1], accE[1][r], accE[1][r + 1]); }
+            else { sp_select2(ba[0], sa[0], accO[0][r], accO[0][r + 1]); sp_select2(ba[1], sa[1], accO[1][r], accO[1][r + 1]); }
+        }
+    }
+#pragma unroll
+    for (int u = 0; u < 2; u++) {
+        sp_fold(ba[u], sa[u], bk[u], sk[u], fbase);
+        const uint32_t obk = __shfl_xor(bk[u], 32), osk = __shfl_xor(sk[u], 32);
+        uint32_t k1 = bk[u], k2 = sk[u];
+        k2 = mf_med3u(k1, k2, obk); k1 = min(k1, obk);
+        k2 = mf_med3u(k1, k2, osk); k1 = min(k1, osk);
+        const int qi = (qb0 + u) * 32 + (lane & 31);
+        if (lane < 32 && qi < nq) part[((long long)bz * nbatch + b) * out_stride + qi] = make_uint2(k1, k2);
+    }
+}
+
+static bool orbm_mfma_sp_on()
+{
+    static const bool on = [] { const char *e = getenv("ORBM_MFMA_SP"); return !e || atoi(e) != 0; }();   // A/B switch, read once
+    return on;
+}
+
 int orbm_mfma_splits(int nq_cap, int nt_cap, int nbatch)
 {
     // parts of the train range per frame pair: enough workgroups for three per CU (one round), a part not shorter than two stages
     const int ttiles = std::max((nt_cap + 31) >> 5, 1);
+    if (orbm_mfma_sp_on()) {      // the pipelined kernel: one workgroup per CU; a part not shorter than two stages
+        const long long wgs = (long long)nbatch * ((((nq_cap + 31) >> 5) + 7) / 8);
+        int S = (int)std::max<long long>((256 + wgs / 2) / std::max<long long>(wgs, 1), 1);
+        static const int forced = [] { const char *e = getenv("ORBM_MFMA_SPLITS"); return e ? std::max(atoi(e), 1) : 0; }();
+        if (forced) S = forced;
+        return std::min(std::min(S, std::max(ttiles / (2 * SP_STG), 1)), 64);
+    }
     const long long wgs = (long long)nbatch * ((((nq_cap + 31) >> 5) + 4 * MF_QB - 1) / (4 * MF_QB));
     int S = (int)std::max<long long>((256 * MF_OCC + wgs - 1) / std::max<long long>(wgs, 1), 1);
     static const int forced = [] { const char *e = getenv("ORBM_MFMA_SPLITS"); return e ? std::max(atoi(e), 1) : 0; }();   // tuning switch, read once
@@ -257,6 +473,15 @@ int orbm_launch_dense_mfma(orbm_matcher *m, const uint8_t *d_q, const int32_t *d
 {
     (void)m;
     const int qtiles = (cap_q + 31) >> 5;
+    if (orbm_mfma_sp_on()) {
+        static const bool attr = [] { return hipFuncSetAttribute(reinterpret_cast<const void *>(k_best2_mfma_sp), hipFuncAttributeMaxDynamicSharedMemorySize, SP_LDS_BYTES) == hipSuccess; }();
+        if (!attr) return ORBX_E_HIP;
+        const int nbx8 = (qtiles + 7) / 8, total8 = nbx8 * S * nbatch;
+        hipLaunchKernelGGL(k_best2_mfma_sp, dim3((unsigned)((total8 + 7) & ~7)), dim3(256), SP_LDS_BYTES, s,
+                           d_q, d_nq, nq_fixed, d_t, d_nt, nt_fixed, qstride, tstride, cap_q, cap_t, out_stride, part, nbx8, S, nbatch, total8);
+        MHIPCHK(hipGetLastError());
+        return ORBX_OK;
+    }
     const int nbx = (qtiles + 4 * MF_QB - 1) / (4 * MF_QB), total = nbx * S * nbatch;
     hipLaunchKernelGGL(k_best2_mfma, dim3((unsigned)((total + 7) & ~7)), dim3(256), 0, s,
                        d_q, d_nq, nq_fixed, d_t, d_nt, nt_fixed, qstride, tstride, cap_q, cap_t, out_stride, part, nbx, S, nbatch, total);

@@ -66,6 +66,9 @@ struct orbx_extractor {
     // several pyramid levels per launch (k_resize_fused): one plan per band height (16 rows for batches, 8 for a few frames)
     struct FusePlan { bool ok = false; int a = 0, b = 0, nbands = 0, buf0 = 0, lds = 0, bh = 0; size_t off = 0; } fuse[2];
     int4 *d_bands = nullptr; size_t bands_cap = 0; int fuse_on = 1; int oct_fast = 1; int oct_cap_max = 0;
+    // upper pyramid levels in one launch, one wave per 2-D tile (k_resize_tiles): levels tile.a + 1 .. nlevels - 1
+    struct TilePlan { bool ok = false; int a = 0, b = 0, ntx = 0, nty = 0, lds = 0; int lds_off[ORBX_FUSE_MAX] = {}, tab_off[ORBX_FUSE_MAX] = {}; size_t offx = 0, offy = 0; } tile;
+    int4 *d_tiles = nullptr; size_t tiles_cap = 0; int tile_a = 0, tile_w = 32, tile_h = 32, tile_min_frames = 8;   // off by default: measured slower than the launches it replaces
     size_t oct_lds = 0;
     // allocations (sized for the max shape)
     OrbxPlan max_plan; size_t pyr_bytes = 0; size_t pyr_level_off[ORBX_MAX_LEVELS];
@@ -222,6 +225,18 @@ static void plan_resize(int sw, int sh, int dw, int dh, int *xofs, short2 *alpha
     int span = 0;
     for (int dx = 0; dx + 3 < dw; dx += 4) span = std::max(span, xofs[dx + 3] + 1 - xofs[dx]);
     *mode = area2 ? RESIZE_AREA2 : (span <= 7 && sw >= 12 ? RESIZE_FAST : RESIZE_GENERIC);
+    // the shared-row kernel (k_resize_linear_4x4s / k_resize_tiles): rows y4 .. y4+3 of every block of four destination rows
+    // start r or r + 1 source rows below the block's first one (true for scale factors up to 4/3) and nothing reflects at the top
+    if (*mode == RESIZE_FAST) {
+        static const bool on = [] { const char *e = getenv("ORBX_RESIZE6"); return !e || atoi(e) != 0; }();   // A/B switch
+        bool six = on && sh >= 2;
+        for (int y4 = 0; y4 < dh && six; y4++) {                 // any first row: k_resize_tiles starts its blocks where a tile's region starts
+            six = yofs[y4] >= 0;
+            for (int r = 1; r < 4 && y4 + r < dh; r++) { const int o = yofs[y4 + r] - yofs[y4]; six = six && (o == r || o == r + 1); }
+        }
+        for (int dx = 0; dx + 3 < dw && six; dx++) six = xofs[dx + 3] + 1 - xofs[dx] <= 7;     // and any first column (the 8-byte window)
+        if (six) *mode = RESIZE_FAST6;
+    }
 }
 
 static void free_all(orbx_extractor *h)
@@ -229,7 +244,7 @@ static void free_all(orbx_extractor *h)
     if (!h) return;
     hipSetDevice(h->device);
     (void)hipHostFree(h->h_pyr);
-    hipFree(h->d_input); hipFree(h->d_pyr); hipFree(h->d_tab_i); hipFree(h->d_tab_s); hipFree(h->d_cells); hipFree(h->d_bands);
+    hipFree(h->d_input); hipFree(h->d_pyr); hipFree(h->d_tab_i); hipFree(h->d_tab_s); hipFree(h->d_cells); hipFree(h->d_bands); hipFree(h->d_tiles);
     hipFree(h->work.cand); hipFree(h->work.cand_count); hipFree(h->work.owner); hipFree(h->work.arena);
     hipFree(h->work.sel); hipFree(h->work.nk); hipFree(h->work.ncand); hipFree(h->work.errflags);
     hipFree(h->d_out);
@@ -302,6 +317,15 @@ extern "C" int orbx_create(orbx_extractor **out, int nfeatures, float scale_fact
     ALLOC(h->d_tab_s, tab_e * sizeof(short2));
     h->bands_cap = 2 * ((size_t)max_height / 8 + 4) * ORBX_MAX_LEVELS;
     ALLOC(h->d_bands, h->bands_cap * sizeof(int4));
+    h->tiles_cap = 8192;
+    ALLOC(h->d_tiles, h->tiles_cap * sizeof(int4));
+    {   // ORBX_PYRAMID_TILES = "a[,tile width[,tile height[,min frames]]]": levels a + 1 .. last in one launch (0 = off = default).
+        // Bit-exact, and at 64 x 640x480 slower than the per-level launches (levels 3..7: 40 us against 27; without any store 30): the
+        // tiles' halos make it compute 1.8x the pixels, two waves per SIMD are all the 1920 tiles give.  Kept as an A/B switch.
+        const char *e = getenv("ORBX_PYRAMID_TILES");
+        if (e) { int a = 2, tw = 32, th = 32, mf = 8; const int n = sscanf(e, "%d,%d,%d,%d", &a, &tw, &th, &mf); if (n >= 1) h->tile_a = a; if (n >= 2) h->tile_w = tw; if (n >= 3) h->tile_h = th; if (n >= 4) h->tile_min_frames = mf; }
+        if (h->tile_w < 8 || h->tile_w > 128 || (h->tile_w & 3) || h->tile_h < 8 || h->tile_h > 128 || (h->tile_h & 3)) h->tile_a = 0;
+    }
     { const char *e = getenv("ORBX_PYRAMID_FUSE"); if (e) h->fuse_on = atoi(e); }
     { const char *e = getenv("ORBX_OVERLAP_PYRAMID"); if (e) h->overlap_pyr = atoi(e) != 0; }   // A/B switch for ORBX_OPT_OVERLAP_PYRAMID
     h->cells_cap = h->max_plan.ncells + 64 * nlevels;   // a smaller frame never has more cells; slack for rounding
@@ -405,6 +429,52 @@ extern "C" int orbx_last_stage_ms(orbx_extractor *h, float ms[4])
     return ORBX_OK;
 }
 
+// One axis of the tile plan of k_resize_tiles.  n[l] = extent of level l, ofs[l] = level l's source-offset table (level-l coordinate ->
+// level l-1 coordinate, monotone), T = tile extent at level b.  out[i * (b - a + 1) + (l - a)] = (own0, own1, comp0, comp1) of tile i at
+// level l: the owned ranges of a level are cut at the images of the level-b tile boundaries , so they partition the level; the computed range is the hull of the owned range
+// and the bilinear footprint of what the tile computes one level down, lengthened to a multiple of 4 (the kernel works in 4x4 blocks
+// counted from the range's first pixel).  align_own (the x axis): the computed range starts a multiple of 4 before the owned one, so
+// that a block is owned from its first column on or not at all (the range may then start at -1 .. -3: the kernel's table slices repeat column 0).
+static int plan_tile_axis(int a, int b, int T, const int *n, const int *const *ofs, bool align_own, std::vector<int4> &out, int *max_comp)
+{
+    const int nt = (n[b] + T - 1) / T, nl = b - a + 1;
+    T = std::min(T, (((n[b] + nt - 1) / nt) + 3) & ~3);       // equal tiles: the kernel ends with its largest tile, and a sliver of a tile carries a full halo
+    out.assign((size_t)nt * nl, make_int4(0, 0, 0, 0));
+    std::vector<std::vector<int>> B((size_t)nl, std::vector<int>((size_t)nt + 1, 0));
+    for (int i = 0; i <= nt; i++) B[(size_t)(b - a)][(size_t)i] = std::min(i * T, n[b]);
+    for (int l = b - 1; l >= a; l--)
+        for (int i = 0; i <= nt; i++) {
+            int v = 0;
+            if (i == nt) v = n[l];
+            else if (i > 0) {
+                const int d = B[(size_t)(l + 1 - a)][(size_t)i];
+                if (d >= n[l + 1]) v = n[l];
+                else v = std::min(std::max(ofs[l + 1][d], 0), n[l] - 1);
+                v = std::max(v, B[(size_t)(l - a)][(size_t)i - 1]);
+            }
+            B[(size_t)(l - a)][(size_t)i] = v;
+        }
+    for (int l = a; l <= b; l++) max_comp[l] = 0;
+    for (int i = 0; i < nt; i++) {
+        int c0 = B[(size_t)(b - a)][(size_t)i], c1 = c0 + ((B[(size_t)(b - a)][(size_t)i + 1] - c0 + 3) & ~3);
+        out[(size_t)i * nl + (size_t)(b - a)] = make_int4(B[(size_t)(b - a)][(size_t)i], B[(size_t)(b - a)][(size_t)i + 1], c0, c1);
+        max_comp[b] = std::max(max_comp[b], c1 - c0);
+        for (int l = b - 1; l >= a; l--) {
+            const int v1 = std::min(c1, n[l + 1]);                     // valid coordinates of the computed range one level down
+            if (v1 <= c0) return -1;
+            const int need0 = std::min(std::max(ofs[l + 1][std::max(c0, 0)], 0), n[l] - 1);
+            const int need1 = std::min(std::max(ofs[l + 1][v1 - 1], 0) + 1, n[l] - 1) + 1;
+            const int o0 = B[(size_t)(l - a)][(size_t)i], o1 = B[(size_t)(l - a)][(size_t)i + 1];
+            c0 = o0 < o1 ? std::min(o0, need0) : need0;
+            if (align_own && o0 < o1) c0 = o0 - ((o0 - c0 + 3) & ~3);                // the owned part starts on a block boundary (c0 may be -1 .. -3)
+            c1 = c0 + (((o0 < o1 ? std::max(o1, need1) : need1) - c0 + 3) & ~3);     // whole 4x4 blocks from the range's first pixel on
+            out[(size_t)i * nl + (size_t)(l - a)] = make_int4(o0, o1, c0, c1);
+            max_comp[l] = std::max(max_comp[l], c1 - c0);
+        }
+    }
+    return nt;
+}
+
 // (re)plan for a frame shape; buffers stay those sized at create
 static int ensure_plan(orbx_extractor *h, int W, int H)
 {
@@ -429,7 +499,7 @@ static int ensure_plan(orbx_extractor *h, int W, int H)
     std::vector<int> ti(h->tab_elems ? h->tab_elems : 1);
     std::vector<short2> ts(h->tab_elems ? h->tab_elems : 1);
     size_t e = 0;
-    size_t yofs_at[ORBX_MAX_LEVELS] = {};
+    size_t yofs_at[ORBX_MAX_LEVELS] = {}, xofs_at[ORBX_MAX_LEVELS] = {};
     for (int l = 1; l < h->nlevels; l++) {
         OrbxLevel &L = P.lv[l];
         L.stride = (int)align_up(L.w, 64);
@@ -439,7 +509,7 @@ static int ensure_plan(orbx_extractor *h, int W, int H)
         const size_t ex = align_up((size_t)L.w + 4, 4), ey = align_up((size_t)L.h + 4, 4);
         plan_resize(S.w, S.h, L.w, L.h, &ti[e], &ts[e], &ti[e + ex], &ts[e + ex], &h->area2[l]);
         for (size_t dy = (size_t)L.h; dy < ey; dy++) { ti[e + ex + dy] = ti[e + ex + L.h - 1]; ts[e + ex + dy] = ts[e + ex + L.h - 1]; }   // k_resize_linear_4x4 reads rows in fours
-        yofs_at[l] = e + ex;
+        yofs_at[l] = e + ex; xofs_at[l] = e;
         h->tabs[l].xofs = h->d_tab_i + e; h->tabs[l].alpha = h->d_tab_s + e;
         h->tabs[l].yofs = h->d_tab_i + e + ex; h->tabs[l].beta = h->d_tab_s + e + ex;
         e += ex + ey;
@@ -461,7 +531,7 @@ static int ensure_plan(orbx_extractor *h, int W, int H)
         const int b = h->nlevels - 1;
         for (int a = 1; h->fuse_on && b - a >= 2 && b < ORBX_FUSE_MAX; a++) {
             bool fast = true;
-            for (int l = a + 1; l <= b; l++) fast = fast && h->area2[l] == RESIZE_FAST && (P.lv[l].w + 3) / 4 <= 512;
+            for (int l = a + 1; l <= b; l++) fast = fast && resize_is_fast(h->area2[l]) && (P.lv[l].w + 3) / 4 <= 512;
             if (!fast) continue;
             const int nl = b - a + 1, nb = (P.lv[b].h + F.bh - 1) / F.bh;
             std::vector<int4> t((size_t)nb * nl);
@@ -496,11 +566,41 @@ static int ensure_plan(orbx_extractor *h, int W, int H)
             break;
         }
     }
+    // ---- fused upper levels, one wave per 2-D tile (k_resize_tiles) ----
+    std::vector<int4> tiles;
+    h->tile = orbx_extractor::TilePlan();
+    {
+        orbx_extractor::TilePlan &T = h->tile;
+        const int b = h->nlevels - 1, a = h->tile_a;
+        bool ok = a >= 1 && b - a >= 2 && b < ORBX_FUSE_MAX;
+        for (int l = a + 1; l <= b && ok; l++) ok = h->area2[l] == RESIZE_FAST6;
+        if (ok) {
+            int nw[ORBX_MAX_LEVELS], nh[ORBX_MAX_LEVELS], mcx[ORBX_MAX_LEVELS], mcy[ORBX_MAX_LEVELS];
+            const int *ox[ORBX_MAX_LEVELS] = {}, *oy[ORBX_MAX_LEVELS] = {};
+            for (int l = a; l <= b; l++) { nw[l] = P.lv[l].w; nh[l] = P.lv[l].h; if (l > a) { ox[l] = &ti[xofs_at[l]]; oy[l] = &ti[yofs_at[l]]; } }
+            std::vector<int4> tx, ty;
+            const int ntx = plan_tile_axis(a, b, h->tile_w, nw, ox, true, tx, mcx), nty = plan_tile_axis(a, b, h->tile_h, nh, oy, false, ty, mcy);
+            ok = ntx >= 1 && nty >= 1 && ntx <= 64 && ntx * nty < 4096 && tx.size() + ty.size() <= h->tiles_cap;
+            int off = 0;
+            for (int l = a + 1; l <= b && ok; l++) {                             // every fused level has its own region in the wave's LDS
+                ok = mcx[l] / 4 <= 64 && (mcx[l] / 4) * mcy[l] < 4096;           // the lane -> block / lane -> dword division table of the kernel
+                T.lds_off[l] = off;
+                off += (int)align_up((size_t)mcy[l] * mcx[l] + ORBX_TILE_SLACK, 16);
+            }
+            for (int l = a + 1; l <= b && ok; l++) { T.tab_off[l] = off; off += 8 * (mcx[l] + mcy[l]); }    // the tile's table slices (mcx, mcy: multiples of 4)
+            if (ok && off <= 60 * 1024) {
+                T.ok = true; T.a = a; T.b = b; T.ntx = ntx; T.nty = nty; T.lds = off;
+                T.offx = 0; T.offy = tx.size();
+                tiles = tx; tiles.insert(tiles.end(), ty.begin(), ty.end());
+            }
+        }
+    }
     P.cell_tab = h->d_cells;
     // a shape change rewrites tables that kernels of an earlier call may still be reading -- on the handle's stream, its aux
     // streams or a caller's stream (orbx_extract_batch_device): wait for the device, not only for h->stream (shape changes are rare)
     HIPCHK(hipDeviceSynchronize());
     if (!bands.empty()) HIPCHK(hipMemcpy(h->d_bands, bands.data(), bands.size() * sizeof(int4), hipMemcpyHostToDevice));
+    if (!tiles.empty()) HIPCHK(hipMemcpy(h->d_tiles, tiles.data(), tiles.size() * sizeof(int4), hipMemcpyHostToDevice));
     HIPCHK(hipMemcpy(h->d_cells, cells.data(), (size_t)P.ncells * sizeof(uint32_t), hipMemcpyHostToDevice));
     HIPCHK(hipMemcpy(h->d_tab_i, ti.data(), e * sizeof(int), hipMemcpyHostToDevice));
     HIPCHK(hipMemcpy(h->d_tab_s, ts.data(), e * sizeof(short2), hipMemcpyHostToDevice));
@@ -585,9 +685,26 @@ static int enqueue(orbx_extractor *h, const uint8_t *d_images, int nframes, int 
             const orbx_extractor::FusePlan *cand = h->fuse[1].ok ? &h->fuse[1] : (h->fuse[0].ok ? &h->fuse[0] : nullptr);
             if (h->fuse_on == 2 && h->fuse[0].ok && (long long)h->fuse[0].nbands * nf >= 384) cand = &h->fuse[0];
             if (cand && (h->fuse_on == 2 || (long long)nf * sp[i].lv[cand->a + 1].w * sp[i].lv[cand->a + 1].h <= 1200000)) F = cand;
-            const int last_single = F ? F->a : h->nlevels - 1;
+            // many frames: the upper levels as one wave per 2-D tile (k_resize_tiles); it takes precedence over the band kernel
+            const bool use_tiles = h->tile.ok && h->fuse_on != 2 && nf >= h->tile_min_frames;
+            if (use_tiles) F = nullptr;
+            const int last_single = use_tiles ? h->tile.a : (F ? F->a : h->nlevels - 1);
             for (int l = 1; l <= last_single; l++)
                 orbx_launch_resize(sp[i].lv[l - 1], sp[i].lv[l], h->tabs[l], h->area2[l], nf, l == 1 ? src_end : nullptr, st[i]);
+            if (use_tiles) {
+                TileArgs A;
+                memset(&A, 0, sizeof(A));
+                A.a = h->tile.a; A.b = h->tile.b; A.ntx = h->tile.ntx; A.nty = h->tile.nty;
+                for (int l = 0; l < ORBX_FUSE_MAX; l++) { A.lds_off[l] = h->tile.lds_off[l]; A.tab_off[l] = h->tile.tab_off[l]; }
+                A.xr = h->d_tiles + h->tile.offx; A.yr = h->d_tiles + h->tile.offy;
+                { static const int dbg = [] { const char *e = getenv("ORBX_TILE_DBG"); return e ? atoi(e) : 0; }(); A.dbg = dbg; }
+                for (int l = A.a; l <= A.b; l++) {
+                    const OrbxLevel &L = sp[i].lv[l];
+                    TileLevel &U = A.lv[l];
+                    U.base = L.base; U.w = L.w; U.h = L.h; U.stride = L.stride; U.frame = L.frame_stride; U.tab = h->tabs[l];
+                }
+                orbx_launch_resize_tiles(A, nf, (size_t)h->tile.lds, st[i]);
+            }
             if (F) {
                 FuseArgs A;
                 memset(&A, 0, sizeof(A));

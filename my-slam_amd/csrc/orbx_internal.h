@@ -141,8 +141,16 @@ struct FuseLevel { uint8_t *base; int w, h, stride; long long frame; ResizeTab t
 struct FuseArgs { FuseLevel lv[ORBX_FUSE_MAX]; int a, b; const int4 *bands; int nbands; int buf0_bytes; };
 void orbx_launch_resize_fused(const FuseArgs &A, int nframes, size_t lds_bytes, hipStream_t s);
 
+// Several pyramid levels in one launch, one WAVE per 2-D tile of level b (orbx_pyramid.hip, k_resize_tiles).  Per axis and per
+// (tile, level l = a .. b): (x, y) = the range of level l this tile writes to memory, (z, w) = the range it computes (multiples of 4).
+#define ORBX_TILE_SLACK 16       // bytes behind a level's region in LDS (the 12-byte source windows of its last row read past it)
+struct TileLevel { uint8_t *base; int w, h, stride; long long frame; ResizeTab tab; };
+struct TileArgs { TileLevel lv[ORBX_FUSE_MAX]; int lds_off[ORBX_FUSE_MAX], tab_off[ORBX_FUSE_MAX]; int a, b, ntx, nty, dbg; const int4 *xr, *yr; };
+void orbx_launch_resize_tiles(const TileArgs &A, int nframes, size_t lds_bytes, hipStream_t s);
+
 // ---- launchers (orbx_pyramid.hip, orbx_fast.hip, orbx_octree.hip, orbx_describe.hip) ----
-enum { RESIZE_FAST = 0, RESIZE_AREA2 = 1, RESIZE_GENERIC = 2 };
+enum { RESIZE_FAST = 0, RESIZE_AREA2 = 1, RESIZE_GENERIC = 2, RESIZE_FAST6 = 3 };   // FAST6: FAST, and a 4-row block touches <= 6 source rows
+static inline bool resize_is_fast(int mode) { return mode == RESIZE_FAST || mode == RESIZE_FAST6; }
 // src_end != NULL: the source is caller-owned memory; one past its last valid byte (fast path guard)
 void orbx_launch_resize(const OrbxLevel &src, const OrbxLevel &dst, const ResizeTab &tab, int mode,
                         int nframes, const uint8_t *src_end, hipStream_t s);

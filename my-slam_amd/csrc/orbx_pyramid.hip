@@ -164,6 +164,141 @@ __global__ __launch_bounds__(256) void k_resize_linear_4x4(
 }
 
 // -------------------------------------------------------------------------------------------------
+// Shared-row 4x4 block (round 3).  For scale factors in (1, 4/3] the four destination rows y4 .. y4+3 of a block touch at most SIX
+// source rows sy0 .. sy0+5 (sy0 = yofs[y4]; yofs[y4 + r] - sy0 is r or r + 1: checked by the planner, RESIZE_FAST6), where the
+// kernel above blends EIGHT row segments horizontally (two per destination row).  Here every source row is blended once:
+//   HH[j][i] = (S[row j][sx_i] * a0_i + S[row j][sx_i + 1] * a1_i) >> 4        6 x 4 values, <= 32640
+// and destination row r takes rows (r, r+1) or (r+1, r+2) of them.  Which pair is a per-lane fact (the blocks of a wave wrap
+// around the row end), so instead of selecting registers the SELECTION RIDES IN THE WEIGHTS: with k = (yofs[y4+r] - sy0 != r),
+//   (w0, w1, w2) = k ? (0, b0, b1) : (b0, b1, 0),   v = ((w0 HH[r] + w2 HH[r+2] + 2 << 16) >> 16) + (w1 HH[r+1] >> 16)
+// is OpenCV's ((b0 * S0 >> 16) + (b1 * S1 >> 16) + 2) exactly (one of w0, w2 is zero; the rounding constant rides in the first
+// product).  The two >> 16, the sum and the final >> 2 are done on u16 PAIRS: v_perm_b32 picks the high halves of two products,
+// v_pk_add_u16, v_pk_lshrrev_b16, and one more v_perm_b32 packs the four bytes of a row: 21 vector instructions per row of four
+// pixels after the 14 per source row, ~230 per block where the kernel above issues ~350.
+// SRC = 0: the source is global memory (S = frame base, absolute rows / columns); SRC = 1: an LDS tile (pitch, rows and
+// columns relative to the tile origin: k_resize_tiles below).
+// -------------------------------------------------------------------------------------------------
+typedef unsigned short rs_us2 __attribute__((ext_vector_type(2)));
+typedef uint32_t rs_u32x3 __attribute__((ext_vector_type(3)));
+typedef rs_u32x3 __attribute__((aligned(4))) rs_U3a4;
+typedef const __attribute__((address_space(1))) uint8_t *rs_gptr;   // explicitly global
+__device__ __forceinline__ uint32_t rs_mad24(uint32_t a, uint32_t b, uint32_t c)   // a * b + c on the 24-bit multiplier (left alone the compiler emits mul + add3)
+{
+    uint32_t d;
+    asm("v_mad_u32_u24 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c));
+    return d;
+}
+__device__ __forceinline__ rs_gptr rs_scalar_ptr(const uint8_t *p)     // a wave-uniform pointer pinned to scalar registers
+{
+    const uint64_t b = reinterpret_cast<uint64_t>(p);
+    const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)b), hi = __builtin_amdgcn_readfirstlane((uint32_t)(b >> 32));
+    return (rs_gptr)(((uint64_t)hi << 32) | lo);
+}
+template <int SRC, bool CHECK>
+__device__ __forceinline__ void resize_block6(const uint8_t *S, int pitch, int row0, int rmax, int col, const uint32_t sel[4], const uint32_t al[4],
+                                              const int4 syv, const uint4 bwv, uint32_t endoff, bool last_frame, uint32_t out[4])
+{
+    uint32_t HH[6][4];
+    {
+        uint32_t wv[6][3], sh8[6];
+        // row j of the block = source row min(row0 + j, rmax): one add and one min per row on the byte offset
+        const uint32_t off0 = (uint32_t)(__mul24(row0, pitch) + col), offmax = (uint32_t)(__mul24(rmax, pitch) + col);
+        const rs_gptr Sg = rs_scalar_ptr(S);
+#pragma unroll
+        for (int j = 0; j < 6; j++) {
+            const uint32_t off = min(off0 + (uint32_t)(j * pitch), offmax);
+            if (SRC == 0) {
+                sh8[j] = ((uint32_t)(uintptr_t)S + off) & 3u;
+                const uint32_t offa = off - sh8[j];
+                if (CHECK && last_frame) {     // only the last frame can end at the end of the caller's buffer
+                    const uint32_t *q = reinterpret_cast<const uint32_t *>(S + offa);
+                    wv[j][0] = q[0];
+                    wv[j][1] = (offa + 8u <= endoff) ? q[1] : 0u;
+                    wv[j][2] = (offa + 12u <= endoff) ? q[2] : 0u;
+                } else {
+                    // (scalar frame base) + (32-bit lane offset): the global_load saddr form, no 64-bit vector arithmetic
+                    const rs_U3a4 q = *(const __attribute__((address_space(1))) rs_U3a4 *)(Sg + offa);
+                    wv[j][0] = q.x; wv[j][1] = q.y; wv[j][2] = q.z;
+                }
+            } else {
+                sh8[j] = off & 3u;
+                const uint32_t *q = reinterpret_cast<const uint32_t *>(S + (off & ~3u));
+                wv[j][0] = q[0]; wv[j][1] = q[1]; wv[j][2] = q[2];
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < 6; j++) {
+            const uint32_t lo = __builtin_amdgcn_alignbyte(wv[j][1], wv[j][0], sh8[j]);
+            const uint32_t hi = __builtin_amdgcn_alignbyte(wv[j][2], wv[j][1], sh8[j]);
+#pragma unroll
+            for (int i = 0; i < 4; i++)
+                HH[j][i] = __builtin_amdgcn_udot2(__builtin_bit_cast(rs_us2, __builtin_amdgcn_perm(hi, lo, sel[i])), __builtin_bit_cast(rs_us2, al[i]), 0u, false) >> 4;
+        }
+    }
+    const int sy4[4] = {syv.x, syv.y, syv.z, syv.w};
+    const uint32_t bw4[4] = {bwv.x, bwv.y, bwv.z, bwv.w};
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+        const uint32_t b0 = bw4[r] & 0xFFFFu, b1 = bw4[r] >> 16;     // 0 .. 2048 (a reduction: both weights are non-negative)
+        uint32_t p[4], q[4];
+        if (r == 0) {
+#pragma unroll
+            for (int i = 0; i < 4; i++) { p[i] = rs_mad24(b0, HH[0][i], 0x20000u); q[i] = __umul24(b1, HH[1][i]); }
+        } else {
+            const uint32_t m = (uint32_t)(r - (sy4[r] - sy4[0]));     // 0: rows (r, r+1); 0xFFFFFFFF: rows (r+1, r+2)
+            const uint32_t w0 = b0 & ~m, w2 = b1 & m, w1 = b1 ^ ((b0 ^ b1) & m);
+#pragma unroll
+            for (int i = 0; i < 4; i++) { p[i] = rs_mad24(w2, HH[r + 2][i], rs_mad24(w0, HH[r][i], 0x20000u)); q[i] = __umul24(w1, HH[r + 1][i]); }
+        }
+        // (p >> 16) + (q >> 16) on u16 pairs, then >> 2, then the four low bytes
+        const rs_us2 z01 = __builtin_bit_cast(rs_us2, __builtin_amdgcn_perm(p[1], p[0], 0x07060302u)) + __builtin_bit_cast(rs_us2, __builtin_amdgcn_perm(q[1], q[0], 0x07060302u));
+        const rs_us2 z23 = __builtin_bit_cast(rs_us2, __builtin_amdgcn_perm(p[3], p[2], 0x07060302u)) + __builtin_bit_cast(rs_us2, __builtin_amdgcn_perm(q[3], q[2], 0x07060302u));
+        const rs_us2 two = {2, 2};
+        out[r] = __builtin_amdgcn_perm(__builtin_bit_cast(uint32_t, z23 >> two), __builtin_bit_cast(uint32_t, z01 >> two), 0x06040200u);
+    }
+}
+
+template <bool CHECK>
+__global__ __launch_bounds__(256) void k_resize_linear_4x4s(
+    const uint8_t *__restrict__ src, int sw, int sh, int sstride, long long sframe,
+    uint8_t *__restrict__ dst, int dw, int dh, int dstride, long long dframe, ResizeTab tab,
+    const uint8_t *src_end, int nbx, int nblk, uint32_t rcp_nbx)
+{
+    const int t = blockIdx.x * 256 + threadIdx.x;     // blocks numbered row-major, dealt linearly (see k_resize_linear_4x4)
+    if (t >= nblk) return;
+    int by = rcp_nbx ? (int)__umulhi((uint32_t)t, rcp_nbx) : t;
+    by -= (by * nbx > t) ? 1 : 0;
+    const int x4 = (t - by * nbx) * 4, y4 = by * 4;
+    const uint8_t *S = src + (long long)blockIdx.z * sframe;
+    uint8_t *D = dst + (long long)blockIdx.z * dframe;
+    const int4 sxv = *reinterpret_cast<const int4 *>(tab.xofs + x4);          // tables are padded to 4
+    const uint4 alv = *reinterpret_cast<const uint4 *>(tab.alpha + x4);
+    const int4 syv = *reinterpret_cast<const int4 *>(tab.yofs + y4);
+    const uint4 bwv = *reinterpret_cast<const uint4 *>(tab.beta + y4);
+    int sx[4] = {sxv.x, sxv.y, sxv.z, sxv.w};
+    uint32_t al[4] = {alv.x, alv.y, alv.z, alv.w}, sel[4], out[4];
+#pragma unroll
+    for (int i = 1; i < 4; i++)
+        if (x4 + i >= dw) { sx[i] = sx[0]; al[i] = al[0]; }
+#pragma unroll
+    for (int i = 0; i < 4; i++) sel[i] = 0x0c010c00u + (uint32_t)(sx[i] - sx[0]) * 0x00010001u;
+    const uint32_t endoff = CHECK ? (uint32_t)(src_end - S) : 0u;
+    resize_block6<0, CHECK>(S, sstride, max(syv.x, 0), sh - 1, sx[0], sel, al, syv, bwv, endoff, CHECK && blockIdx.z == gridDim.z - 1, out);
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+        const int y = y4 + r;
+        if (y >= dh) break;
+        uint8_t *Dr = D + (uint32_t)(__mul24(y, dstride) + x4);
+        if (x4 + 3 < dw) *reinterpret_cast<uint32_t *>(Dr) = out[r];
+        else {
+            Dr[0] = (uint8_t)out[r];
+            if (x4 + 1 < dw) Dr[1] = (uint8_t)(out[r] >> 8);
+            if (x4 + 2 < dw) Dr[2] = (uint8_t)(out[r] >> 16);
+        }
+    }
+}
+
+// -------------------------------------------------------------------------------------------------
 // Levels a+1 .. b in ONE launch.  The upper levels of the pyramid are small (level 7 of a 640 x 480 frame is 179 x 134): as
 // launches of their own each costs the ~4.5 us launch floor for 0.3 .. 4 us of work, six of them in a row.  Level l + 1 is a pure
 // function of level l's integer output (:1117-1123), so a workgroup that holds a band of rows of level l in LDS can produce the
@@ -348,6 +483,217 @@ void orbx_launch_resize_fused(const FuseArgs &A, int nframes, size_t lds_bytes, 
     hipLaunchKernelGGL(k_resize_fused, dim3(A.nbands, nframes), dim3(512), lds_bytes, s, A);
 }
 
+// -------------------------------------------------------------------------------------------------
+// Levels a+1 .. b in ONE launch, second form (round 3): ONE WAVE = one 2-D tile of level b and everything above it.
+// The band kernel above makes a workgroup of 8 waves walk six barrier-separated phases over full-width bands; its waves wait for
+// each other at every level and it measured slower than the launches it replaces at batch 64.  Here a wave owns a TW x TH tile of
+// level b of one frame and the region of every level a+1 .. b-1 that the tile's bilinear footprints reach; it computes level l+1
+// of its region from level l of its region in its PRIVATE LDS (two buffers, alternating), so nothing but the wave's own LDS
+// instructions orders the levels: no workgroup barrier, no other wave to wait for, and the ~2000 waves of a 64-frame batch drift
+// through their levels independently, one wave's LDS latency under another's arithmetic.  Every level is written to memory
+// by exactly one tile: the x and y OWNED ranges of the tiles partition each level (images of the level-b tile grid under the
+// monotone xofs / yofs maps), the COMPUTED ranges (owned + footprint of the next level's computed range, lengthened to a multiple
+// of 4: the arithmetic works in 4x4 blocks counted from the range's own first pixel) overlap and are computed twice (+30 % pixels on
+// these small levels; rounding the ranges outwards to multiples of 4 in level coordinates, the first version, made it +90 %).  Planned on the host per axis (plan_tile_axis in orbx_capi.hip).
+// Arithmetic: resize_block6 on 4x4 blocks, blocks of the tile's region dealt to the 64 lanes.  Needs RESIZE_FAST6 on every fused level
+// and a >= 1 (the source of the first fused level is a pyramid level with slack behind its rows, never the caller's level 0).
+// -------------------------------------------------------------------------------------------------
+__constant__ uint32_t c_rs_rcp20[65] = {      // (1 << 20) / n + 1: idx / n == (idx * rcp) >> 20 for idx < 4096, n <= 64
+    0, 1048577, 524289, 349526, 262145, 209716, 174763, 149797, 131073, 116509, 104858, 95326, 87382, 80660, 74899, 69906,
+    65537, 61681, 58255, 55189, 52429, 49933, 47663, 45591, 43691, 41944, 40330, 38837, 37450, 36158, 34953, 33826,
+    32769, 31776, 30841, 29960, 29128, 28340, 27595, 26887, 26215, 25576, 24967, 24386, 23832, 23302, 22796, 22311,
+    21846, 21400, 20972, 20561, 20165, 19785, 19419, 19066, 18725, 18397, 18079, 17773, 17477, 17190, 16913, 16645, 16385};
+
+#define RS_WSYNC()                                             \
+    do {                                                       \
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); \
+        asm volatile("" ::: "memory");                         \
+        __builtin_amdgcn_wave_barrier();                       \
+        asm volatile("" ::: "memory");                         \
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); \
+    } while (0)
+
+typedef int rs_i32x4 __attribute__((ext_vector_type(4)));
+
+// The tile's slices of level l's four tables, copied to the wave's LDS once (all levels, before any arithmetic): xofs and yofs RELATIVE to
+// the source region's origin, columns past the level's last one (and before its first: a region may start up to three columns left
+// of 0 so that its owned part starts on a block boundary) as copies of the nearest valid column.  With the tables in LDS the loops of
+// the LDS-to-LDS levels hold no vector memory LOAD at all, so their stores to memory are never waited for.
+// Layout at tab: xofs[cw] | alpha[cw] | yofs[ch] | beta[ch]  (cw, ch multiples of 4: every block reads four entries with one ds_read_b128).
+__device__ __forceinline__ void tile_stage_tabs(const TileLevel &D, const int4 X, const int4 Y, int orgx, int orgy, int lane, int *tab)
+{
+    const int cw = X.w - X.z, ch = Y.w - Y.z;
+    for (int i = lane; i < cw; i += 64) {
+        const int x = min(max(X.z + i, 0), D.w - 1);
+        tab[i] = D.tab.xofs[x] - orgx;
+        tab[cw + i] = *reinterpret_cast<const int *>(D.tab.alpha + x);
+    }
+    for (int i = lane; i < ch; i += 64) {
+        const int y = min(max(Y.z + i, 0), D.h - 1);
+        tab[2 * cw + i] = D.tab.yofs[y] - orgy;
+        tab[2 * cw + ch + i] = *reinterpret_cast<const int *>(D.tab.beta + y);
+    }
+}
+
+// level l of the tile's region from level l - 1 (memory for the first fused level, the wave's LDS otherwise) into the wave's LDS, and
+// -- STORE -- the owned pixels to memory straight from the registers.  The first fused level reads its source from memory: a store
+// between two loads of its loop would put its acknowledgement (~1 us) on the path of the next load (vector memory operations retire
+// in order), so that level's owned pixels go out in a pass of their own after the loop (tile_writeout).
+template <int SRC, bool STORE>
+__device__ __forceinline__ void tile_level(const TileArgs &A, int l, const int4 Xs, const int4 Ys, const int4 X, const int4 Y, int f, int lane,
+                                           const uint8_t *sbuf, uint8_t *dbuf, const int *tab)
+{
+    const TileLevel &Sv = A.lv[l - 1], &D = A.lv[l];
+    const int cw = X.w - X.z, ch = Y.w - Y.z;
+    const int nbx = cw >> 2, nblk = nbx * (ch >> 2);
+    const uint32_t rcp = c_rs_rcp20[nbx];
+    const int ps = SRC == 0 ? Sv.stride : (Xs.w - Xs.z), pd = cw;
+    const uint8_t *S = SRC == 0 ? Sv.base + (long long)f * Sv.frame : sbuf;
+    const int orgy = SRC == 0 ? 0 : Ys.z;
+    // last source row a block may touch: the level's last row, and in LDS also the region's last row (a block reads six rows whatever it
+    // uses; the ones past the region carry zero weights)
+    const int rmax = SRC == 0 ? Sv.h - 1 : min(Sv.h - 1 - orgy, (Ys.w - Ys.z) - 1);
+    const int x1 = min(X.y, D.w);                                   // one past the last column this tile stores
+    uint8_t *Dg = D.base + (long long)f * D.frame;
+    for (int it = lane; it < nblk; it += 64) {
+        const int by = (int)(__umul24((uint32_t)it, rcp) >> 20), bx = it - by * nbx;
+        const rs_i32x4 a = *reinterpret_cast<const rs_i32x4 *>(tab + 4 * bx), b = *reinterpret_cast<const rs_i32x4 *>(tab + cw + 4 * bx);
+        const rs_i32x4 c = *reinterpret_cast<const rs_i32x4 *>(tab + 2 * cw + 4 * by), d = *reinterpret_cast<const rs_i32x4 *>(tab + 2 * cw + ch + 4 * by);
+        const uint32_t al[4] = {(uint32_t)b.x, (uint32_t)b.y, (uint32_t)b.z, (uint32_t)b.w};
+        uint32_t sel[4], out[4];
+        sel[0] = 0x0c010c00u;
+        sel[1] = 0x0c010c00u + (uint32_t)(a.y - a.x) * 0x00010001u;
+        sel[2] = 0x0c010c00u + (uint32_t)(a.z - a.x) * 0x00010001u;
+        sel[3] = 0x0c010c00u + (uint32_t)(a.w - a.x) * 0x00010001u;
+        resize_block6<SRC, false>(S, ps, c.x, rmax, a.x, sel, al, make_int4(c.x, c.y, c.z, c.w), make_uint4((uint32_t)d.x, (uint32_t)d.y, (uint32_t)d.z, (uint32_t)d.w), 0u, false, out);
+        uint32_t *dp = reinterpret_cast<uint32_t *>(dbuf + (uint32_t)(__mul24(4 * by, pd) + 4 * bx));
+#pragma unroll
+        for (int r = 0; r < 4; r++) dp[r * (pd >> 2)] = out[r];
+        if (STORE && !(A.dbg & 2)) {
+            const int x4 = X.z + 4 * bx, y4 = Y.z + 4 * by;
+            if (x4 >= X.x && x4 < x1) {                             // the owned columns start on a block boundary (planner); they end anywhere
+                typedef uint32_t __attribute__((aligned(1))) u32a1;
+                uint8_t *Dr = Dg + (uint32_t)(__mul24(y4, D.stride) + x4);
+                if (x4 + 3 < x1) {
+#pragma unroll
+                    for (int r = 0; r < 4; r++)
+                        if (y4 + r >= Y.x && y4 + r < Y.y) *reinterpret_cast<u32a1 *>(Dr + r * D.stride) = out[r];
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 4; r++)
+                        if (y4 + r >= Y.x && y4 + r < Y.y) {
+                            uint8_t *q = Dr + r * D.stride;
+                            q[0] = (uint8_t)out[r];
+                            if (x4 + 1 < x1) q[1] = (uint8_t)(out[r] >> 8);
+                            if (x4 + 2 < x1) q[2] = (uint8_t)(out[r] >> 16);
+                        }
+                }
+            }
+        }
+    }
+}
+
+// the owned part of level l: LDS -> memory, rows of dwords from the first owned column on (neither the LDS offset nor the address
+// in memory is a multiple of 4 in general: two aligned LDS dwords funnel-shifted, one unaligned store); four dwords per lane in
+// flight so that the LDS latency is paid once per four stores
+__device__ __forceinline__ void tile_writeout(const TileLevel &D, const int4 X, const int4 Y, int f, int lane, const uint8_t *buf)
+{
+    const int x1 = min(X.y, D.w);
+    const int nd = (x1 - X.x + 3) >> 2, rows = Y.y - Y.x;
+    if (nd <= 0 || rows <= 0) return;
+    const int n = nd * rows, pd = X.w - X.z;
+    const uint32_t rcp = c_rs_rcp20[nd];
+    uint8_t *Dg = D.base + (long long)f * D.frame;
+    for (int i0 = lane; i0 < n; i0 += 256) {
+        uint32_t v[4]; int xs[4], ys[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const int i = min(i0 + 64 * k, n - 1);
+            const int r = (int)(__umul24((uint32_t)i, rcp) >> 20), d = i - r * nd;
+            ys[k] = Y.x + r; xs[k] = X.x + 4 * d;
+            const uint32_t o = (uint32_t)(__mul24(ys[k] - Y.z, pd) + (xs[k] - X.z));
+            const uint32_t *q = reinterpret_cast<const uint32_t *>(buf + (o & ~3u));
+            v[k] = __builtin_amdgcn_alignbyte(q[1], q[0], o & 3u);
+        }
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            if (i0 + 64 * k >= n) break;
+            uint8_t *Dr = Dg + (uint32_t)(__mul24(ys[k], D.stride) + xs[k]);
+            typedef uint32_t __attribute__((aligned(1))) u32a1;
+            if (xs[k] + 3 < x1) *reinterpret_cast<u32a1 *>(Dr) = v[k];
+            else {
+                Dr[0] = (uint8_t)v[k];
+                if (xs[k] + 1 < x1) Dr[1] = (uint8_t)(v[k] >> 8);
+                if (xs[k] + 2 < x1) Dr[2] = (uint8_t)(v[k] >> 16);
+            }
+        }
+    }
+}
+
+ORBX_TRACE_DEFINE(g_tile_trace, orbx_debug_tile_trace)
+#ifdef ORBX_TRACE          // start / end of every wave on the 100 MHz wall clock + the XCC / CU it ran on (tools/dbg/tile_trace.py)
+__device__ unsigned long long g_tile_span[3 * 8192];
+extern "C" int orbx_debug_tile_span(unsigned long long *out) { return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_tile_span), sizeof(g_tile_span)); }
+#define TILE_SPAN(i, v) do { if (lane == 0 && lb < 8192) g_tile_span[3 * lb + (i)] = (v); } while (0)
+#else
+#define TILE_SPAN(i, v) do { } while (0)
+#endif
+__global__ __launch_bounds__(64) void k_resize_tiles(TileArgs A, int ntiles, int total, uint32_t rcp_ntiles)
+{
+    extern __shared__ __attribute__((aligned(16))) uint8_t tile_lds[];
+    const int lane = threadIdx.x;
+    ORBX_TRACE_DECL;
+    // contiguous eighths of the (frame, tile) list per XCD: the tiles of a frame share their source halos in one L2 (placement only)
+    const int lb = (int)(blockIdx.x & 7u) * (int)(gridDim.x >> 3) + (int)(blockIdx.x >> 3);
+    if (lb >= total) return;
+    TILE_SPAN(0, wall_clock64());
+#ifdef ORBX_TRACE
+    { uint32_t hwid, xcc; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid)); asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc)); TILE_SPAN(2, ((unsigned long long)xcc << 32) | hwid); }
+#endif
+    int f = rcp_ntiles ? (int)__umulhi((uint32_t)lb, rcp_ntiles) : lb;
+    f -= (f * ntiles > lb) ? 1 : 0;
+    const int t = lb - f * ntiles;
+    // the tile's ranges are wave-uniform: pinned to scalar registers so that they arrive by scalar loads (a vector load here would
+    // wait behind every store the wave has issued: vector memory operations retire in order)
+    const int tj = __builtin_amdgcn_readfirstlane((int)(__umul24((uint32_t)t, c_rs_rcp20[A.ntx]) >> 20));
+    const int ti = __builtin_amdgcn_readfirstlane(t) - tj * A.ntx;
+    const int nl = A.b - A.a + 1;
+    // (constant address space + uniform index = s_load_dwordx4)
+    typedef const __attribute__((address_space(4))) rs_i32x4 *rs_cptr4;
+    const rs_cptr4 xrc = (rs_cptr4)(uintptr_t)(A.xr + ti * nl), yrc = (rs_cptr4)(uintptr_t)(A.yr + tj * nl);
+    auto xr = [&](int k) { const rs_i32x4 v = xrc[k]; return make_int4(v.x, v.y, v.z, v.w); };
+    auto yr = [&](int k) { const rs_i32x4 v = yrc[k]; return make_int4(v.x, v.y, v.z, v.w); };
+    // every level's table slices -> LDS (one batch of loads, one wait)
+    for (int l = A.a + 1; l <= A.b; l++) {
+        const int4 Xp = xr(l - 1 - A.a), Yp = yr(l - 1 - A.a);
+        tile_stage_tabs(A.lv[l], xr(l - A.a), yr(l - A.a), l == A.a + 1 ? 0 : Xp.z, l == A.a + 1 ? 0 : Yp.z, lane, reinterpret_cast<int *>(tile_lds + A.tab_off[l]));
+    }
+    RS_WSYNC();
+    int4 Xs = xr(0), Ys = yr(0);
+    for (int l = A.a + 1; l <= A.b; l++) {
+        const int4 X = xr(l - A.a), Y = yr(l - A.a);
+        const uint8_t *sbuf = tile_lds + A.lds_off[l - 1];
+        uint8_t *dbuf = tile_lds + A.lds_off[l];
+        const int *tab = reinterpret_cast<const int *>(tile_lds + A.tab_off[l]);
+        if (l == A.a + 1) tile_level<0, false>(A, l, Xs, Ys, X, Y, f, lane, sbuf, dbuf, tab);
+        else tile_level<1, true>(A, l, Xs, Ys, X, Y, f, lane, sbuf, dbuf, tab);
+        Xs = X; Ys = Y;
+        RS_WSYNC();
+        if (l == A.a + 1 && !(A.dbg & 1)) tile_writeout(A.lv[l], X, Y, f, lane, dbuf);      // no vector load follows in this wave: nothing waits for these stores
+        ORBX_TRACE_STAMP(min(l - A.a - 1, 4));
+    }
+    ORBX_TRACE_STAMP(5);
+    TILE_SPAN(1, wall_clock64());
+    ORBX_TRACE_FLUSH(g_tile_trace);
+}
+
+void orbx_launch_resize_tiles(const TileArgs &A, int nframes, size_t lds_bytes, hipStream_t s)
+{
+    const int ntiles = A.ntx * A.nty, total = ntiles * nframes;
+    const uint32_t rcp = ntiles > 1 ? (uint32_t)((1ull << 32) / (unsigned)ntiles + 1) : 0u;
+    hipLaunchKernelGGL(k_resize_tiles, dim3((unsigned)((total + 7) & ~7)), dim3(64), lds_bytes, s, A, ntiles, total, rcp);
+}
+
 void orbx_launch_resize(const OrbxLevel &src, const OrbxLevel &dst, const ResizeTab &tab, int mode,
                         int nframes, const uint8_t *src_end, hipStream_t s)
 {
@@ -363,7 +709,14 @@ void orbx_launch_resize(const OrbxLevel &src, const OrbxLevel &dst, const Resize
         const int nbx = (dst.w + 3) / 4, nblk = nbx * ((dst.h + 3) / 4);
         const uint32_t rcp = nbx > 1 ? (uint32_t)((1ull << 32) / (unsigned)nbx + 1) : 0u;
         dim3 grid((nblk + 255) / 256, 1, nframes);
-        if (src_end)
+        if (mode == RESIZE_FAST6) {
+            if (src_end)
+                hipLaunchKernelGGL(k_resize_linear_4x4s<true>, grid, dim3(256), 0, s, src.base, src.w, src.h, src.stride,
+                                   src.frame_stride, dst.base, dst.w, dst.h, dst.stride, dst.frame_stride, tab, src_end, nbx, nblk, rcp);
+            else
+                hipLaunchKernelGGL(k_resize_linear_4x4s<false>, grid, dim3(256), 0, s, src.base, src.w, src.h, src.stride,
+                                   src.frame_stride, dst.base, dst.w, dst.h, dst.stride, dst.frame_stride, tab, src_end, nbx, nblk, rcp);
+        } else if (src_end)
             hipLaunchKernelGGL(k_resize_linear_4x4<true>, grid, dim3(256), 0, s, src.base, src.w, src.h, src.stride,
                                src.frame_stride, dst.base, dst.w, dst.h, dst.stride, dst.frame_stride, tab, src_end, nbx, nblk, rcp);
         else

@@ -62,6 +62,20 @@ def test_pyramid_and_candidates_match_oracle(orbx, synth):
         assert gset == oset, "level %d candidates differ (%d vs %d)" % (l, len(gset), len(oset))
 
 
+@pytest.mark.parametrize("cfg,W,H", [("2,32,32,1", 640, 480), ("1,24,24,1", 1241, 376), ("3,40,16,1", 322, 241)])
+def test_pyramid_tile_kernel_switch(orbx, synth, monkeypatch, cfg, W, H):
+    """ORBX_PYRAMID_TILES: the upper levels in one launch, one wave per 2-D tile (k_resize_tiles; off by default, it measured slower):
+    every level byte-equal to the oracle's pyramid whatever the first fused level and the tile shape."""
+    monkeypatch.setenv("ORBX_PYRAMID_TILES", cfg)
+    img = synth.texture(11, W, H)
+    ex = orbx.ORBextractor(1000, max_width=W, max_height=H)
+    ex(img)
+    opyr = O.Extractor(1000).pyramid(img)
+    pyr = ex.image_pyramid()
+    for l in range(8):
+        assert np.array_equal(pyr[l], opyr[l]), "level %d differs (tiles %s)" % (l, cfg)
+
+
 def test_batch_equals_single(orbx, synth):
     frames = synth.stream(4, 640, 480, 4)
     ex = orbx.ORBextractor(1000, max_width=640, max_height=480, max_batch=4)
