@@ -13,6 +13,7 @@
 #include <vector>
 
 #include "orbm_internal.h"
+#include "orbm_accept.h"
 
 static thread_local std::string g_merr;
 int mfail(int code, const char *fmt, ...)
@@ -122,9 +123,6 @@ int orbm_sync(orbm_matcher *m, hipStream_t s)
 // (best key, second key) with key = distance << 22 | train index, so "strictly smaller wins, first
 // index wins a tie, a tie with the best becomes the second best" (src/ORBmatcher.cc:214-223) is
 // min / median on keys and partials merge exactly (k_merge_best2 / k_accept_rot). ----
-#define M_KEY_NONE ((256u << 22) | 0x3FFFFFu)
-__device__ __forceinline__ uint32_t med3u(uint32_t a, uint32_t b, uint32_t c) { return max(min(a, b), min(max(a, b), c)); }
-
 #define M_TILE 128   // train descriptors staged per LDS tile (4 KiB)
 __global__ __launch_bounds__(M_THREADS) void k_best2_dense(
     const uint8_t *__restrict__ q, const int32_t *__restrict__ nqv, int nq_fixed,
@@ -164,32 +162,6 @@ __global__ __launch_bounds__(M_THREADS) void k_best2_dense(
         cnt = ncnt;
     }
     if (qi < nq) part[((long long)blockIdx.z * gridDim.y + b) * out_stride + qi] = make_uint2(bk, sk);
-}
-
-// merge the train-range partials of one query: the two smallest keys of the union
-__device__ __forceinline__ void merge_partial_keys(const uint2 *__restrict__ part, int S, long long stride_z, long long o,
-                                                   uint32_t &bk, uint32_t &sk)
-{
-    bk = M_KEY_NONE; sk = M_KEY_NONE;
-    for (int z0 = 0; z0 < S; z0 += 8) {   // eight partials per round trip (a load per iteration would be one memory latency each)
-        uint2 p[8];
-#pragma unroll
-        for (int u = 0; u < 8; u++) p[u] = z0 + u < S ? part[(long long)(z0 + u) * stride_z + o] : make_uint2(M_KEY_NONE, M_KEY_NONE);
-#pragma unroll
-        for (int u = 0; u < 8; u++) {
-            sk = med3u(bk, sk, p[u].x); bk = min(bk, p[u].x);
-            sk = med3u(bk, sk, p[u].y); bk = min(bk, p[u].y);
-        }
-    }
-}
-__device__ __forceinline__ void merge_partials(const uint2 *__restrict__ part, int S, long long stride_z, long long o,
-                                               int &bi, int &bd, int &sd)
-{
-    uint32_t bk, sk;
-    merge_partial_keys(part, S, stride_z, o, bk, sk);
-    bd = (int)(bk >> 22);
-    sd = (int)(sk >> 22);
-    bi = bd < 256 ? (int)(bk & 0x3FFFFFu) : -1;
 }
 
 __global__ __launch_bounds__(M_THREADS) void k_merge_best2(const uint2 *__restrict__ part, int S, int nq,
@@ -301,125 +273,16 @@ __global__ __launch_bounds__(M_THREADS) void k_merge_keys(const uint2 *__restric
     merged[o] = make_uint2(bk, sk);
 }
 
-// ---- acceptance (:228-232) + rotation histogram (:236-246) + ComputeThreeMaxima + cull (:266-284) ----
-__device__ __forceinline__ int rot_bin(float a1, float a2)
-{
-    const float factor = 1.0f / 30;
-    float rot = __fsub_rn(a1, a2);
-    if (rot < 0.0f) rot = __fadd_rn(rot, 360.0f);
-    int bin = (int)roundf(__fmul_rn(rot, factor));
-    if (bin == 30) bin = 0;
-    return bin;
-}
-
-__device__ __forceinline__ void three_maxima(const int *histo, int L, int &ind1, int &ind2, int &ind3)
-{
-    int max1 = 0, max2 = 0, max3 = 0;
-    ind1 = ind2 = ind3 = -1;
-    for (int i = 0; i < L; i++) {
-        const int s = histo[i];
-        if (s > max1) { max3 = max2; max2 = max1; max1 = s; ind3 = ind2; ind2 = ind1; ind1 = i; }
-        else if (s > max2) { max3 = max2; max2 = s; ind3 = ind2; ind2 = i; }
-        else if (s > max3) { max3 = s; ind3 = i; }
-    }
-    if ((float)max2 < 0.1f * (float)max1) { ind2 = -1; ind3 = -1; }
-    else if ((float)max3 < 0.1f * (float)max1) { ind3 = -1; }
-}
-
-// One 1024-thread workgroup per frame pair; every thread keeps its (up to ACC_PER_THREAD) queries in
-// registers across the histogram barrier, so the kernel is two dependent global round trips
-// (partials -> matched keypoint angle) instead of a chain per loop iteration.
-#define ACC_THREADS 1024
-#define ACC_PER_THREAD 4
+// ---- acceptance (:228-232) + rotation histogram (:236-246) + ComputeThreeMaxima + cull (:266-284): orbm_accept.h ----
 __global__ __launch_bounds__(ACC_THREADS) void k_accept_rot(
     const int32_t *__restrict__ nqv, const orbx_keypoint *__restrict__ kq, const orbx_keypoint *__restrict__ kt,
     int cap, const uint2 *__restrict__ part, int S, int th, float nnratio, int check_ori,
     int32_t *__restrict__ match12, int32_t *__restrict__ nmatches,
     int32_t *__restrict__ best_idx, int32_t *__restrict__ best_d, int32_t *__restrict__ second_d)
 {
-    __shared__ int hist[32];
-    __shared__ int s_ind[3];
-    __shared__ int s_count;
-    const int b = blockIdx.x, tid = threadIdx.x;
-    const int nq = nqv[b];
-    const long long base = (long long)b * cap;
-    const long long stride_z = (long long)gridDim.x * cap;
-    if (tid < 32) hist[tid] = 0;
-    if (tid == 0) s_count = 0;
-    __syncthreads();
-    int cnt = 0;
-    for (int i0 = 0; i0 < nq; i0 += ACC_THREADS * ACC_PER_THREAD) {
-        int mm[ACC_PER_THREAD], bins[ACC_PER_THREAD];
-        float aq[ACC_PER_THREAD];
-#pragma unroll
-        for (int u = 0; u < ACC_PER_THREAD; u++) {
-            const int i = i0 + u * ACC_THREADS + tid;
-            mm[u] = -1; bins[u] = -1; aq[u] = 0.f;
-            if (i < nq) {
-                int bi, bd, sd;
-                merge_partials(part, S, stride_z, base + i, bi, bd, sd);
-                if (best_idx) { best_idx[base + i] = bi; best_d[base + i] = bd; second_d[base + i] = sd; }
-                if (bd <= th && (float)bd < __fmul_rn(nnratio, (float)sd)) mm[u] = bi;     // :228-232
-                if (check_ori) aq[u] = kq[base + i].angle;
-            }
-        }
-#pragma unroll
-        for (int u = 0; u < ACC_PER_THREAD; u++)
-            if (mm[u] >= 0 && check_ori) {
-                bins[u] = rot_bin(aq[u], kt[base + mm[u]].angle);
-                atomicAdd(&hist[bins[u]], 1);
-            }
-        if (nq > ACC_THREADS * ACC_PER_THREAD) {
-            // more queries than one sweep holds in registers: park (match, bin) in match12 and redo below
-#pragma unroll
-            for (int u = 0; u < ACC_PER_THREAD; u++) {
-                const int i = i0 + u * ACC_THREADS + tid;
-                if (i < nq) match12[base + i] = mm[u] >= 0 ? (mm[u] | (max(bins[u], 0) << 24)) : -1;
-            }
-        } else {
-            __syncthreads();
-            if (tid == 0) {
-                int i1, i2, i3;
-                three_maxima(hist, 30, i1, i2, i3);
-                s_ind[0] = i1; s_ind[1] = i2; s_ind[2] = i3;
-            }
-            __syncthreads();
-#pragma unroll
-            for (int u = 0; u < ACC_PER_THREAD; u++) {
-                const int i = i0 + u * ACC_THREADS + tid;
-                if (i < nq) {
-                    int m = mm[u];
-                    if (m >= 0 && check_ori && bins[u] != s_ind[0] && bins[u] != s_ind[1] && bins[u] != s_ind[2]) m = -1;
-                    match12[base + i] = m;
-                    cnt += m >= 0;
-                }
-            }
-        }
-    }
-    if (nq > ACC_THREADS * ACC_PER_THREAD) {   // large-frame path (train index < 2^22: cap <= 0x3FFFFF is checked on the host)
-        __syncthreads();
-        if (tid == 0) {
-            int i1, i2, i3;
-            three_maxima(hist, 30, i1, i2, i3);
-            s_ind[0] = i1; s_ind[1] = i2; s_ind[2] = i3;
-        }
-        __syncthreads();
-        for (int i = tid; i < nq; i += ACC_THREADS) {
-            const int pk = match12[base + i];
-            int m = -1;
-            if (pk >= 0) {
-                m = pk & 0xFFFFFF;
-                const int bin = pk >> 24;
-                if (check_ori && bin != s_ind[0] && bin != s_ind[1] && bin != s_ind[2]) m = -1;
-            }
-            match12[base + i] = m;
-            cnt += m >= 0;
-        }
-    }
-    for (int i = nq + tid; i < cap; i += ACC_THREADS) match12[base + i] = -1;
-    if (cnt) atomicAdd(&s_count, cnt);
-    __syncthreads();
-    if (tid == 0) nmatches[b] = s_count;
+    __shared__ AcceptShared sh;
+    accept_rot_body<ACC_THREADS>(sh, (int)blockIdx.x, (int)gridDim.x, (int)threadIdx.x, nqv, kq, kt, cap, part, S, th, nnratio, check_ori,
+                                 match12, nmatches, best_idx, best_d, second_d);
 }
 
 // -------------------------------------------------------------------------------------------------
@@ -671,6 +534,9 @@ extern "C" int orbm_match_batch_device(orbm_matcher *m, const uint8_t *d_q, cons
     MHIPCHK(hipSetDevice(m->device));
     hipStream_t s = hip_stream ? (hipStream_t)hip_stream : m->stream;
     int S = 1;
+    // (The acceptance as the tail of the LAST workgroup of a pair inside the match launch -- arrival counter, agent-scope release /
+    // acquire -- was built and measured in round 3: identical tables, 76.7 us against 22.9 + 6.6: every workgroup's release is an L2
+    // write-back on this multi-XCD part.  It stays a launch of its own.)
     int rc = launch_dense_batch(m, d_q, d_nq, d_t, d_nt, cap, nbatch, s, &S);
     if (rc != ORBX_OK) return rc;
     const uint2 *part = m->d_part;

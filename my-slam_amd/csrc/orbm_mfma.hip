@@ -20,6 +20,7 @@
 // k_merge_best2 / k_merge_keys / k_accept_rot are shared.
 #include <algorithm>
 #include <cstdlib>
+#include <cstring>
 #include "orbm_internal.h"
 
 typedef int v4i __attribute__((ext_vector_type(4)));
@@ -224,16 +225,18 @@ __global__ __launch_bounds__(256, MF_OCC) void k_best2_mfma(const uint8_t *__res
         buf ^= 1;
     }
     if (!active) return;
+    {
 #pragma unroll
-    for (int u = 0; u < MF_QB; u++) {
-        mf_fold(ba[u], sa[u], bk[u], sk[u], c0);
-        // lanes l and l + 32 hold the two halves of the rows of one query column
-        const uint32_t obk = __shfl_xor(bk[u], 32), osk = __shfl_xor(sk[u], 32);
-        uint32_t k1 = bk[u], k2 = sk[u];
-        k2 = mf_med3u(k1, k2, obk); k1 = min(k1, obk);
-        k2 = mf_med3u(k1, k2, osk); k1 = min(k1, osk);
-        const int qi = (qb0 + u) * 32 + (lane & 31);
-        if (lane < 32 && qi < nq) part[((long long)bz * nbatch + b) * out_stride + qi] = make_uint2(k1, k2);
+        for (int u = 0; u < MF_QB; u++) {
+            mf_fold(ba[u], sa[u], bk[u], sk[u], c0);
+            // lanes l and l + 32 hold the two halves of the rows of one query column
+            const uint32_t obk = __shfl_xor(bk[u], 32), osk = __shfl_xor(sk[u], 32);
+            uint32_t k1 = bk[u], k2 = sk[u];
+            k2 = mf_med3u(k1, k2, obk); k1 = min(k1, obk);
+            k2 = mf_med3u(k1, k2, osk); k1 = min(k1, osk);
+            const int qi = (qb0 + u) * 32 + (lane & 31);
+            if (lane < 32 && qi < nq) part[((long long)bz * nbatch + b) * out_stride + qi] = make_uint2(k1, k2);
+        }
     }
     MF_STAMP(2);
 }
@@ -257,7 +260,23 @@ __global__ __launch_bounds__(256, MF_OCC) void k_best2_mfma(const uint8_t *__res
 //     workgroups = 252 for the 256 CUs.
 // Same operands, same partial format, same tie rules as above; tests/test_matcher_gpu.py runs both.
 // -------------------------------------------------------------------------------------------------
-#define SP_STG 4                          // tiles per LDS stage (even: the accumulator parity of a tile is then a compile-time fact)
+#ifdef SP_TRACE      // per-phase shader-clock totals over the workgroups (wave 0): 0 prologue, 1 tiles, 2 expand (+ the wait for the stage's loads), 3 barrier, 4 epilogue, 7 = workgroups
+__device__ unsigned long long g_sp_trace[8];
+__device__ unsigned long long g_sp_span[2 * 1024];      // start / end of workgroup lb on the 100 MHz wall clock
+extern "C" int orbm_debug_sp_span(unsigned long long *out) { return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_sp_span), sizeof(g_sp_span)); }
+extern "C" int orbm_debug_sp_trace(unsigned long long *out, int reset)
+{
+    static unsigned long long z[8];
+    if (reset) return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_sp_trace), z, sizeof(z));
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_sp_trace), sizeof(z));
+}
+#define SP_T(i) do { const unsigned long long n_ = __builtin_readcyclecounter(); spt_acc[i] += n_ - spt_last; spt_last = n_; } while (0)
+#else
+#define SP_T(i) do { } while (0)
+#endif
+#ifndef SP_STG
+#define SP_STG 4
+#endif                                    // tiles per LDS stage (even: the accumulator parity of a tile is then a compile-time fact)
 #define SP_LDS_BYTES (2 * SP_STG * 512 * 16 + 256 * 8)
 
 // second largest of {ba >= sa, x, y} and the largest, 3 instructions for two elements
@@ -285,7 +304,7 @@ __device__ __forceinline__ void sp_fold(int &ba, int &sa, uint32_t &bk, uint32_t
     ba = MF_ACC_NONE; sa = MF_ACC_NONE;
 }
 
-__global__ __launch_bounds__(256, 1) void k_best2_mfma_sp(const uint8_t *__restrict__ q, const int32_t *__restrict__ nqv, int nq_fixed,
+__global__ __launch_bounds__(256, 2) void k_best2_mfma_sp(const uint8_t *__restrict__ q, const int32_t *__restrict__ nqv, int nq_fixed,
                                                           const uint8_t *__restrict__ t, const int32_t *__restrict__ ntv, int nt_fixed,
                                                           long long qstride, long long tstride, int cap_q, int cap_t, int out_stride,
                                                           uint2 *__restrict__ part, int nbx, int S, int nbatch, int total)
@@ -294,6 +313,10 @@ __global__ __launch_bounds__(256, 1) void k_best2_mfma_sp(const uint8_t *__restr
     uint2 *lut = reinterpret_cast<uint2 *>(sp_lds + 2 * SP_STG * 512);
     const int lb = (int)(blockIdx.x & 7u) * (int)(gridDim.x >> 3) + (int)(blockIdx.x >> 3);
     if (lb >= total) return;
+#ifdef SP_TRACE
+    unsigned long long spt_last = __builtin_readcyclecounter(), spt_acc[5] = {0, 0, 0, 0, 0};
+    if (threadIdx.x == 0 && lb < 1024) g_sp_span[2 * lb] = wall_clock64();
+#endif
     const int b = lb / (nbx * S), rem = lb - b * (nbx * S), bz = rem / nbx, bx = rem - bz * nbx;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int qb0 = (bx * 4 + wave) * 2;
@@ -356,79 +379,77 @@ __global__ __launch_bounds__(256, 1) void k_best2_mfma_sp(const uint8_t *__restr
     __syncthreads();
 
     const int h4 = 4 * (lane >> 5);
-    v16i init0, accE[2], accO[2];
+    v16i init0;
 #pragma unroll
-    for (int r = 0; r < 16; r++) { init0[r] = -(h4 + (r & 3) + 8 * (r >> 2)); accO[0][r] = MF_ACC_NONE; accO[1][r] = MF_ACC_NONE; }
+    for (int r = 0; r < 16; r++) init0[r] = -(h4 + (r & 3) + 8 * (r >> 2));
     int ba[2] = {MF_ACC_NONE, MF_ACC_NONE}, sa[2] = {MF_ACC_NONE, MF_ACC_NONE};
     uint32_t bk[2] = {MF_KEY_NONE, MF_KEY_NONE}, sk[2] = {MF_KEY_NONE, MF_KEY_NONE};
-    int fbase = t0 * 32, pbase = t0 * 32, chunk0 = t0 * 32;      // frame of (ba, sa); first row of the pending tile; first row of the chunk
-    int lastpar = 1;                                             // parity of the accumulator set that is pending (accO holds nothing real yet)
+    int fbase = t0 * 32, chunk0 = t0 * 32;           // first row of the tile (ba, sa) are relative to; first row of the chunk
 
-    // one tile: its 16 MFMAs into CUR, the selection of the pending tile (PRV) in their gaps
-#define SP_STEP(CUR, PRV, BASE)                                                                                          \
+    // One tile: the eight A operands of the NEXT tile are requested first (AN), then this tile's 16 MFMAs run on operands that
+    // arrived during the previous tile (AC), then its selection.  (Read two at a time right before their MFMAs -- what the
+    // compiler makes of a plain loop -- every tile pays the LDS latency four times: 2.4 k clocks per tile and wave against 512 of MFMA.)
+#define SP_TILE(AC, AN, J)                                                                                               \
     do {                                                                                                                 \
-        if (pbase - chunk0 >= MF_CHUNK) {                      /* rare: > 4096 train rows */                             \
+        const int base_ = (tt + (J)) * 32;                                                                               \
+        if ((J) + 1 < SP_STG && tt + (J) + 1 < t1) {                                                                     \
+            const uint4 *N_ = sp_lds + (size_t)buf * (SP_STG * 512) + ((J) + 1) * 512;                                   \
+            _Pragma("unroll") for (int s = 0; s < 8; s++) AN[s] = __builtin_bit_cast(v4i, N_[s * 64 + lane]);            \
+        }                                                                                                                \
+        __builtin_amdgcn_sched_barrier(0);                                                                               \
+        if (base_ - chunk0 >= MF_CHUNK) {                      /* rare: > 4096 train rows */                             \
             sp_fold(ba[0], sa[0], bk[0], sk[0], fbase); sp_fold(ba[1], sa[1], bk[1], sk[1], fbase);                      \
-            chunk0 = pbase;                                                                                              \
+            chunk0 = base_;                                                                                              \
         }                                                                                                                \
-        const int delta_ = pbase - fbase;                                                                                \
+        const int delta_ = base_ - fbase;                                                                                \
         ba[0] += delta_; sa[0] += delta_; ba[1] += delta_; sa[1] += delta_;                                              \
-        fbase = pbase;                                                                                                   \
+        fbase = base_;                                                                                                   \
         v16i ini_ = init0;                                                                                               \
-        if ((BASE) + 32 > nt) {                                /* last, partial tile: rows beyond the train count never win */ \
+        if (base_ + 32 > nt) {                                 /* last, partial tile: rows beyond the train count never win */ \
             _Pragma("unroll") for (int r = 0; r < 16; r++)                                                               \
-                if ((BASE) + h4 + (r & 3) + 8 * (r >> 2) >= nt) ini_[r] = MF_ROW_NONE;                                   \
+                if (base_ + h4 + (r & 3) + 8 * (r >> 2) >= nt) ini_[r] = MF_ROW_NONE;                                    \
         }                                                                                                                \
-        v4i a_[8];                                                                                                       \
-        _Pragma("unroll") for (int s = 0; s < 8; s++) a_[s] = __builtin_bit_cast(v4i, A_[s * 64 + lane]);                \
-        CUR[0] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a_[0], bq[0][0], ini_, 0, 0, 0);                                  \
-        CUR[1] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a_[0], bq[1][0], ini_, 0, 0, 0);                                  \
+        v16i acc0_ = __builtin_amdgcn_mfma_i32_32x32x32_i8(AC[0], bq[0][0], ini_, 0, 0, 0);                              \
+        v16i acc1_ = __builtin_amdgcn_mfma_i32_32x32x32_i8(AC[0], bq[1][0], ini_, 0, 0, 0);                              \
         _Pragma("unroll") for (int s = 1; s < 8; s++) {                                                                  \
-            CUR[0] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a_[s], bq[0][s], CUR[0], 0, 0, 0);                            \
-            CUR[1] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a_[s], bq[1][s], CUR[1], 0, 0, 0);                            \
+            acc0_ = __builtin_amdgcn_mfma_i32_32x32x32_i8(AC[s], bq[0][s], acc0_, 0, 0, 0);                              \
+            acc1_ = __builtin_amdgcn_mfma_i32_32x32x32_i8(AC[s], bq[1][s], acc1_, 0, 0, 0);                              \
         }                                                                                                                \
         _Pragma("unroll") for (int r = 0; r < 16; r += 2) {                                                              \
-            sp_select2(ba[0], sa[0], PRV[0][r], PRV[0][r + 1]);                                                          \
-            sp_select2(ba[1], sa[1], PRV[1][r], PRV[1][r + 1]);                                                          \
+            sp_select2(ba[0], sa[0], acc0_[r], acc0_[r + 1]);                                                            \
+            sp_select2(ba[1], sa[1], acc1_[r], acc1_[r + 1]);                                                            \
         }                                                                                                                \
-        _Pragma("unroll") for (int g = 0; g < 16; g++) {       /* MFMA, 3 vector instructions, MFMA, ... */              \
-            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                                           \
-            __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);                                                           \
-        }                                                                                                                \
-        pbase = (BASE);                                                                                                  \
     } while (0)
 
     int buf = 0;
+    v4i aE[8], aO[8];
+    SP_T(0);
     for (int tt = t0; tt < t1; tt += SP_STG) {
         const bool more = tt + SP_STG < t1;
         if (more) load_stage(tt + SP_STG, t1);                  // in flight during this stage's MFMAs
         if (active) {
+            const uint4 *F_ = sp_lds + (size_t)buf * (SP_STG * 512);     // the stage's first tile: nothing to overlap its reads with
 #pragma unroll
-            for (int j = 0; j < SP_STG; j++) {
-                if (tt + j >= t1) break;
-                const uint4 *A_ = sp_lds + (size_t)buf * (SP_STG * 512) + j * 512;
-                if ((j & 1) == 0) { SP_STEP(accE, accO, (tt + j) * 32); lastpar = 0; }
-                else { SP_STEP(accO, accE, (tt + j) * 32); lastpar = 1; }
-            }
+            for (int s = 0; s < 8; s++) aE[s] = __builtin_bit_cast(v4i, F_[s * 64 + lane]);
+            SP_TILE(aE, aO, 0);
+            if (tt + 1 < t1) SP_TILE(aO, aE, 1);
+#if SP_STG == 4
+            if (tt + 2 < t1) SP_TILE(aE, aO, 2);
+            if (tt + 3 < t1) SP_TILE(aO, aE, 3);
+#endif
+            static_assert(SP_STG == 4 || SP_STG == 2, "the tile sequence above is written out for two or four tiles per stage");
         }
+        SP_T(1);
         if (more) {
             expand_stage(tt + SP_STG, buf ^ 1);
+            SP_T(2);
             __syncthreads();
+            SP_T(3);
         }
         buf ^= 1;
     }
-#undef SP_STEP
+#undef SP_TILE
     if (!active) return;
-    {   // the pending tile, then the chunk
-        const int delta = pbase - fbase;
-        ba[0] += delta; sa[0] += delta; ba[1] += delta; sa[1] += delta;
-        fbase = pbase;
-#pragma unroll
-        for (int r = 0; r < 16; r += 2) {
-            if (lastpar == 0) { sp_select2(ba[0], sa[0], accE[0][r], accE[0][r + 1]); sp_select2(ba[1], sa[1], accE[1][r], accE[1][r + 1]); }
-            else { sp_select2(ba[0], sa[0], accO[0][r], accO[0][r + 1]); sp_select2(ba[1], sa[1], accO[1][r], accO[1][r + 1]); }
-        }
-    }
 #pragma unroll
     for (int u = 0; u < 2; u++) {
         sp_fold(ba[u], sa[u], bk[u], sk[u], fbase);
@@ -439,11 +460,15 @@ __global__ __launch_bounds__(256, 1) void k_best2_mfma_sp(const uint8_t *__restr
         const int qi = (qb0 + u) * 32 + (lane & 31);
         if (lane < 32 && qi < nq) part[((long long)bz * nbatch + b) * out_stride + qi] = make_uint2(k1, k2);
     }
+#ifdef SP_TRACE
+    SP_T(4);
+    if (tid == 0) { for (int i = 0; i < 5; i++) atomicAdd(&g_sp_trace[i], spt_acc[i]); atomicAdd(&g_sp_trace[7], 1ull); if (lb < 1024) g_sp_span[2 * lb + 1] = wall_clock64(); }
+#endif
 }
 
 static bool orbm_mfma_sp_on()
 {
-    static const bool on = [] { const char *e = getenv("ORBM_MFMA_SP"); return !e || atoi(e) != 0; }();   // A/B switch, read once
+    static const bool on = [] { const char *e = getenv("ORBM_MFMA_SP"); return e && atoi(e) != 0; }();   // A/B switch, read once; off: measured slower (header comment)
     return on;
 }
 
@@ -453,7 +478,7 @@ int orbm_mfma_splits(int nq_cap, int nt_cap, int nbatch)
     const int ttiles = std::max((nt_cap + 31) >> 5, 1);
     if (orbm_mfma_sp_on()) {      // the pipelined kernel: one workgroup per CU; a part not shorter than two stages
         const long long wgs = (long long)nbatch * ((((nq_cap + 31) >> 5) + 7) / 8);
-        int S = (int)std::max<long long>((256 + wgs / 2) / std::max<long long>(wgs, 1), 1);
+        int S = (int)std::max<long long>((512 + wgs / 2) / std::max<long long>(wgs, 1), 1);     // two workgroups per CU
         static const int forced = [] { const char *e = getenv("ORBM_MFMA_SPLITS"); return e ? std::max(atoi(e), 1) : 0; }();
         if (forced) S = forced;
         return std::min(std::min(S, std::max(ttiles / (2 * SP_STG), 1)), 64);
