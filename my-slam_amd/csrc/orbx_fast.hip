@@ -190,22 +190,47 @@ __global__ __launch_bounds__(FAST_THREADS) void k_fast_cells(OrbxPlan plan, Orbx
                        : NDW == 13 ? (int)(__umul24((uint32_t)lane, 79u) >> 10)
                                    : (int)(__umul24((uint32_t)lane, 57u) >> 10);   // lane / NDW, lane < 64
         const int cdw = lane - r_in * NDW;
+        constexpr int NPASS = (TH + RPP - 1) / RPP;
         if (l == 0 && !l0_aligned) {
             const uint8_t *src = img + (iniX - 1) + 4 * cdw;
             if (r_in < RPP && cdw < ndw) {
-                for (int r = r_in; r < th; r += RPP) {
-                    const uintptr_t pa = reinterpret_cast<uintptr_t>(src + (long long)r * L.stride);
-                    const uint32_t *g2 = reinterpret_cast<const uint32_t *>(pa & ~(uintptr_t)3);
-                    *reinterpret_cast<uint32_t *>(&S.tile[r * TS + FAST_PADL + 4 * cdw]) = __builtin_amdgcn_alignbyte(g2[1], g2[0], (uint32_t)pa & 3u);
+                uint32_t lo[NPASS], hi[NPASS], shv[NPASS];
+#pragma unroll
+                for (int i = 0; i < NPASS; i++) {
+                    const int r = r_in + i * RPP;
+                    lo[i] = hi[i] = shv[i] = 0u;
+                    if (r < th) {
+                        const uintptr_t pa = reinterpret_cast<uintptr_t>(src + (long long)r * L.stride);
+                        const uint32_t *g2 = reinterpret_cast<const uint32_t *>(pa & ~(uintptr_t)3);
+                        lo[i] = g2[0]; hi[i] = g2[1]; shv[i] = (uint32_t)pa & 3u;
+                    }
+                }
+#pragma unroll
+                for (int i = 0; i < NPASS; i++) {
+                    const int r = r_in + i * RPP;
+                    if (r < th) *reinterpret_cast<uint32_t *>(&S.tile[r * TS + FAST_PADL + 4 * cdw]) = __builtin_amdgcn_alignbyte(hi[i], lo[i], shv[i]);
                 }
             }
         } else {
+            // every pass's load is issued before the first one is used: one memory round trip for the tile instead of one per pass
+            // (a loop of load / wait / store spent 8.5 k of a wave's 27.8 k clocks here, -DORBX_TRACE)
             const uint32_t sh = (uint32_t)(iniX - 1) & 3u;
             const uint8_t *src = img + ((iniX - 1) & ~3) + 4 * cdw;
             if (r_in < RPP && cdw < ndw) {
-                for (int r = r_in; r < th; r += RPP) {
-                    const uint32_t *g2 = reinterpret_cast<const uint32_t *>(src + (long long)r * L.stride);
-                    *reinterpret_cast<uint32_t *>(&S.tile[r * TS + FAST_PADL + 4 * cdw]) = __builtin_amdgcn_alignbyte(g2[1], g2[0], sh);
+                uint32_t lo[NPASS], hi[NPASS];
+#pragma unroll
+                for (int i = 0; i < NPASS; i++) {
+                    const int r = r_in + i * RPP;
+                    lo[i] = hi[i] = 0u;
+                    if (r < th) {
+                        const uint32_t *g2 = reinterpret_cast<const uint32_t *>(src + (long long)r * L.stride);
+                        lo[i] = g2[0]; hi[i] = g2[1];
+                    }
+                }
+#pragma unroll
+                for (int i = 0; i < NPASS; i++) {
+                    const int r = r_in + i * RPP;
+                    if (r < th) *reinterpret_cast<uint32_t *>(&S.tile[r * TS + FAST_PADL + 4 * cdw]) = __builtin_amdgcn_alignbyte(hi[i], lo[i], sh);
                 }
             }
         }
