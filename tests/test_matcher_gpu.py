@@ -116,3 +116,16 @@ def test_match_batch_device(orbx, cap, nqs, nts):
         assert nmh[b] == on
         assert np.array_equal(m12h[b, :nqs[b]], om)
         assert (m12h[b, nqs[b]:] == -1).all()
+
+
+def test_mfma_operand_prefetch_variant_in_fresh_process():
+    """ORBM_MFMA_SP=1 selects k_best2_mfma_sp (a whole tile's A operands prefetched, running best / second kept relative to the
+    tile in hand; slower at the bench shape).  The switch is read once per process, so the dense and batched
+    parity cases of this file run again in a process of their own with it set."""
+    import os, subprocess, sys
+    env = dict(os.environ, ORBM_MFMA_SP="1")
+    here = os.path.abspath(__file__)
+    p = subprocess.run([sys.executable, "-m", "pytest", here, "-q", "-x", "-m", "gpu", "-k", "test_best2_dense or test_match_batch_device or test_extract_then_match"],
+                       env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=600, cwd=os.path.dirname(os.path.dirname(here)))
+    assert p.returncode == 0, p.stdout[-2000:]
+    assert " passed" in p.stdout and "failed" not in p.stdout

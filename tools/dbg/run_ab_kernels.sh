@@ -1,5 +1,5 @@
 #!/bin/bash
-# generic A/B: extractor parity, then rocprofv3 kernel averages of the bench step (current build)
+# A/B of a build (on the GPU box): extractor parity, then rocprofv3 per-kernel averages and ms_per_step of the bench step, twice
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 O=gpurun_out/r3ab; mkdir -p $O
 timeout -k 10 600 python3 -m pytest tests/test_extractor_gpu.py tests/test_stereo_gpu.py -m gpu -x -q > $O/pytest.log 2>&1; rc=$?; tail -3 $O/pytest.log
