@@ -699,6 +699,19 @@ def main():
                 # command, corrected as MI355X_MICROARCH.md prescribes) over the step time of THIS run
                 "whole_path_measured_bytes_per_step": traffic_all,
                 "whole_path_measured_GBps": round(traffic_all / (elapsed / args.steps) / 1e9, 2) if traffic_all else None}
+        # The ceiling this path actually runs into is vector-instruction issue, not HBM: the dominant kernel's
+        # SQ_INSTS_VALU per launch (profiles/valu_insts.json, a PMC pass of this command) over its launch time measured in THIS run,
+        # against 256 CUs x 4 SIMDs x 2.4 GHz / 4 clocks per wave instruction (the rate of most of the instructions it is made of).
+        vf = os.path.join(ROOT, "profiles", "valu_insts.json")
+        if os.path.exists(vf) and (W, H, NF, nown) == (640, 480, 1000, 64):
+            try:
+                vi = json.load(open(vf)).get(dom)
+                if vi:
+                    peak_issue = 256 * 4 * 2.4e9 / 4
+                    roof["valu_issue"] = {"kernel": dom, "wave_insts_per_launch": int(vi), "achieved_Ginst_per_s": round(vi / (stage[dom] * 1e-3) / 1e9, 1),
+                                          "peak_Ginst_per_s": round(peak_issue / 1e9, 1), "frac": round(vi / (stage[dom] * 1e-3) / peak_issue, 4)}
+            except Exception:
+                pass
 
     # ---- extras (N = 1 only; reported beside the contract's line, never as `value`) ----
     pipelined = host_api = extra = cpu = None
