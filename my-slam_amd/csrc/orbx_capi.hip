@@ -697,7 +697,6 @@ static int enqueue(orbx_extractor *h, const uint8_t *d_images, int nframes, int 
                 A.a = h->tile.a; A.b = h->tile.b; A.ntx = h->tile.ntx; A.nty = h->tile.nty;
                 for (int l = 0; l < ORBX_FUSE_MAX; l++) { A.lds_off[l] = h->tile.lds_off[l]; A.tab_off[l] = h->tile.tab_off[l]; }
                 A.xr = h->d_tiles + h->tile.offx; A.yr = h->d_tiles + h->tile.offy;
-                { static const int dbg = [] { const char *e = getenv("ORBX_TILE_DBG"); return e ? atoi(e) : 0; }(); A.dbg = dbg; }
                 for (int l = A.a; l <= A.b; l++) {
                     const OrbxLevel &L = sp[i].lv[l];
                     TileLevel &U = A.lv[l];

@@ -145,7 +145,7 @@ void orbx_launch_resize_fused(const FuseArgs &A, int nframes, size_t lds_bytes, 
 // (tile, level l = a .. b): (x, y) = the range of level l this tile writes to memory, (z, w) = the range it computes (multiples of 4).
 #define ORBX_TILE_SLACK 16       // bytes behind a level's region in LDS (the 12-byte source windows of its last row read past it)
 struct TileLevel { uint8_t *base; int w, h, stride; long long frame; ResizeTab tab; };
-struct TileArgs { TileLevel lv[ORBX_FUSE_MAX]; int lds_off[ORBX_FUSE_MAX], tab_off[ORBX_FUSE_MAX]; int a, b, ntx, nty, dbg; const int4 *xr, *yr; };
+struct TileArgs { TileLevel lv[ORBX_FUSE_MAX]; int lds_off[ORBX_FUSE_MAX], tab_off[ORBX_FUSE_MAX]; int a, b, ntx, nty; const int4 *xr, *yr; };
 void orbx_launch_resize_tiles(const TileArgs &A, int nframes, size_t lds_bytes, hipStream_t s);
 
 // ---- launchers (orbx_pyramid.hip, orbx_fast.hip, orbx_octree.hip, orbx_describe.hip) ----

@@ -569,7 +569,7 @@ __device__ __forceinline__ void tile_level(const TileArgs &A, int l, const int4 
         uint32_t *dp = reinterpret_cast<uint32_t *>(dbuf + (uint32_t)(__mul24(4 * by, pd) + 4 * bx));
 #pragma unroll
         for (int r = 0; r < 4; r++) dp[r * (pd >> 2)] = out[r];
-        if (STORE && !(A.dbg & 2)) {
+        if (STORE) {
             const int x4 = X.z + 4 * bx, y4 = Y.z + 4 * by;
             if (x4 >= X.x && x4 < x1) {                             // the owned columns start on a block boundary (planner); they end anywhere
                 typedef uint32_t __attribute__((aligned(1))) u32a1;
@@ -679,7 +679,7 @@ __global__ __launch_bounds__(64) void k_resize_tiles(TileArgs A, int ntiles, int
         else tile_level<1, true>(A, l, Xs, Ys, X, Y, f, lane, sbuf, dbuf, tab);
         Xs = X; Ys = Y;
         RS_WSYNC();
-        if (l == A.a + 1 && !(A.dbg & 1)) tile_writeout(A.lv[l], X, Y, f, lane, dbuf);      // no vector load follows in this wave: nothing waits for these stores
+        if (l == A.a + 1) tile_writeout(A.lv[l], X, Y, f, lane, dbuf);      // no vector load follows in this wave: nothing waits for these stores
         ORBX_TRACE_STAMP(min(l - A.a - 1, 4));
     }
     ORBX_TRACE_STAMP(5);
