@@ -45,20 +45,6 @@ __device__ __forceinline__ int rot_bin(float a1, float a2)
     return bin;
 }
 
-__device__ __forceinline__ void three_maxima(const int *histo, int L, int &ind1, int &ind2, int &ind3)
-{
-    int max1 = 0, max2 = 0, max3 = 0;
-    ind1 = ind2 = ind3 = -1;
-    for (int i = 0; i < L; i++) {
-        const int s = histo[i];
-        if (s > max1) { max3 = max2; max2 = max1; max1 = s; ind3 = ind2; ind2 = ind1; ind1 = i; }
-        else if (s > max2) { max3 = max2; max2 = s; ind3 = ind2; ind2 = i; }
-        else if (s > max3) { max3 = s; ind3 = i; }
-    }
-    if ((float)max2 < 0.1f * (float)max1) { ind2 = -1; ind3 = -1; }
-    else if ((float)max3 < 0.1f * (float)max1) { ind3 = -1; }
-}
-
 // One workgroup of NT threads per frame pair; every thread keeps its (up to ACC_PER_THREAD) queries in registers across the histogram
 // barrier, so the body is two dependent global round trips (partials -> matched keypoint angle) instead of a chain per loop
 // iteration.  ComputeThreeMaxima runs on the lanes of one wave: the reference's scan (strict '>' in index order) ranks the bins by
