@@ -129,3 +129,40 @@ def test_mfma_operand_prefetch_variant_in_fresh_process():
                        env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=600, cwd=os.path.dirname(os.path.dirname(here)))
     assert p.returncode == 0, p.stdout[-2000:]
     assert " passed" in p.stdout and "failed" not in p.stdout
+
+
+@pytest.mark.parametrize("counts", [
+    {0: 5, 3: 5, 7: 5, 9: 5},                 # four-way tie: the three lowest bins win (strict '>' in index order)
+    {2: 100, 5: 9, 8: 9},                     # second < 10 % of the first: only the first bin survives
+    {2: 100, 5: 10, 8: 9},                    # second exactly 10 %: kept; third below: dropped
+    {11: 7, 1: 7, 6: 3, 4: 3, 12: 1},         # ties at two ranks
+    {0: 1},                                   # one match only
+    {4: 40, 5: 40, 6: 40, 7: 39, 8: 41},      # the maximum comes last in index order
+])
+def test_rotation_histogram_ties_and_ten_percent_rule(orbx, counts):
+    """ComputeThreeMaxima (src/ORBmatcher.cc:1601-1642) inside k_accept_rot runs as three wave-wide maxima: rotation histograms with
+    ties and with bins on both sides of the 10 % rule, built from perfect matches whose angle differences fall in chosen bins."""
+    import torch
+    rng = np.random.default_rng(sum(k * v for k, v in counts.items()) + 17)
+    n = sum(counts.values())
+    cap = max(n, 64)
+    desc = np.zeros((cap, 32), np.uint8)
+    desc[:n] = rng.integers(0, 256, (n, 32), dtype=np.uint8)
+    for i in range(n):                                                     # far apart: every query's best is its own copy, the second best is far
+        desc[i, :4] = np.frombuffer(np.uint32(i * 2654435761 % (1 << 32)).tobytes(), np.uint8)
+    bins = np.concatenate([np.full(v, k) for k, v in counts.items()]).astype(np.int32)
+    rng.shuffle(bins)
+    kq = np.zeros((1, cap), orbx.KP_DTYPE); kt = np.zeros((1, cap), orbx.KP_DTYPE)
+    kt[0]["angle"][:n] = rng.uniform(0, 25, n).astype(np.float32)
+    kq[0]["angle"][:n] = (kt[0]["angle"][:n] + np.float32(30.0) * bins.astype(np.float32)) % np.float32(360.0)   # rot = 30 * bin (bins 0..12)
+    q = desc[None].copy(); t = desc[None].copy()
+    dq, dt = torch.from_numpy(q).cuda(), torch.from_numpy(t).cuda()
+    dkq = torch.from_numpy(kq.view(np.float32).reshape(1, cap, 7)).cuda(); dkt = torch.from_numpy(kt.view(np.float32).reshape(1, cap, 7)).cuda()
+    dn = torch.tensor([n], dtype=torch.int32).cuda()
+    m12 = torch.zeros((1, cap), dtype=torch.int32).cuda(); nm = torch.zeros(1, dtype=torch.int32).cuda()
+    m = orbx.ORBmatcher(0.9, True, max_queries=cap, max_train=cap, max_pairs=1)
+    m.match_batch_device(dq.data_ptr(), dkq.data_ptr(), dn.data_ptr(), dt.data_ptr(), dkt.data_ptr(), dn.data_ptr(), cap, 1, m12.data_ptr(), nm.data_ptr())
+    torch.cuda.synchronize()
+    on, om = O.match_dense(q[0, :n], kq[0]["angle"][:n], t[0, :n], kt[0]["angle"][:n], 50, 0.9, True)
+    assert on > 0 and int(nm.cpu()[0]) == on
+    assert np.array_equal(m12.cpu().numpy()[0, :n], om)
