@@ -24,6 +24,9 @@ __constant__ uint4 c_mom_tab[256];
 // << 10 | first column << 21 | (second row exists) << 27.  0xFFFFFFFF = no task.
 __constant__ uint32_t c_row_task[192];
 __constant__ uint32_t c_col_task[320];
+// The same eight words per lane as two 16-byte entries: [lane] = (row task 0..2, column task 0), [64 + lane] = (column task 1..4).
+// The L1 takes a 64-lane load as 16 four-lane accesses whatever its width: two wide loads cost a quarter of eight narrow ones.
+__constant__ uint4 c_task8[128];
 // rBRIEF sample pairs as floats: (x0, x1, y0, y1) of bit b -- the int8 -> float conversions done once on the host
 __constant__ float4 c_pat_f[256];
 
@@ -79,6 +82,12 @@ int orbx_upload_constants(const int umax[16], const int gauss_k[7])
         for (; nc < 320; nc++) ct[nc] = 0xFFFFFFFFu;
         if (hipMemcpyToSymbol(HIP_SYMBOL(c_row_task), rt, sizeof(rt)) != hipSuccess) return -1;
         if (hipMemcpyToSymbol(HIP_SYMBOL(c_col_task), ct, sizeof(ct)) != hipSuccess) return -1;
+        static uint4 t8[128];
+        for (int ln = 0; ln < 64; ln++) {
+            t8[ln] = make_uint4(rt[ln], rt[64 + ln], rt[128 + ln], ct[ln]);
+            t8[64 + ln] = make_uint4(ct[64 + ln], ct[128 + ln], ct[192 + ln], ct[256 + ln]);
+        }
+        if (hipMemcpyToSymbol(HIP_SYMBOL(c_task8), t8, sizeof(t8)) != hipSuccess) return -1;
     }
     static float4 pf[256];
     for (int b = 0; b < 256; b++)
@@ -254,11 +263,14 @@ __device__ __forceinline__ int wave_sum_dpp(int v)
 ORBX_TRACE_DEFINE(g_desc_trace, orbx_debug_desc_trace)
 
 // 8 waves per SIMD: 63 VGPRs (68 without the bound) and 14 KB of LDS per workgroup; this kernel hides its latencies with resident waves
-__global__ __launch_bounds__(256, 8) void k_describe(
+#ifndef DESC_WAVES
+#define DESC_WAVES 4   // waves (keypoints) per workgroup
+#endif
+__global__ __launch_bounds__(64 * DESC_WAVES, 8) void k_describe(
     OrbxPlan plan, OrbxWork wk, orbx_keypoint *__restrict__ kps, uint8_t *__restrict__ desc,
     int32_t *__restrict__ counts, int32_t *__restrict__ status, int l0_aligned, int wg_per_frame, int nwg, uint32_t wg_rcp)
 {
-    __shared__ DescLds lds[4];
+    __shared__ DescLds lds[DESC_WAVES];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     // XCD x (workgroups x, x + 8, ...) takes the x-th contiguous eighth of the (frame, keypoint) list: the patches of
@@ -268,7 +280,7 @@ __global__ __launch_bounds__(256, 8) void k_describe(
     // lb / wg_per_frame without the integer-division expansion: multiply by floor(2^32 / d) + 1, one correction step
     int f = wg_rcp ? (int)__umulhi((uint32_t)lb, wg_rcp) : lb;   // wg_rcp == 0: one workgroup per frame
     f -= (f * wg_per_frame > lb) ? 1 : 0;
-    const int g = (lb - f * wg_per_frame) * 4 + wave;
+    const int g = (lb - f * wg_per_frame) * DESC_WAVES + wave;
     DescLds &S = lds[wave];
     ORBX_TRACE_DECL;
 
@@ -307,16 +319,55 @@ __global__ __launch_bounds__(256, 8) void k_describe(
 #pragma unroll
     for (int it = 0; it < 4; it++) mom[it] = c_mom_tab[it * 64 + lane];
     uint32_t rtask[3], ctask[5];
+#ifndef DESC_NO_TASK8
+    {
+        const uint4 ta = c_task8[lane], tb = c_task8[64 + lane];
+        rtask[0] = ta.x; rtask[1] = ta.y; rtask[2] = ta.z;
+        ctask[0] = ta.w; ctask[1] = tb.x; ctask[2] = tb.y; ctask[3] = tb.z; ctask[4] = tb.w;
+    }
+#else
 #pragma unroll
     for (int it = 0; it < 3; it++) rtask[it] = c_row_task[it * 64 + lane];
 #pragma unroll
     for (int it = 0; it < 5; it++) ctask[it] = c_col_task[it * 64 + lane];
+#endif
 
     // ---- raw tile -> LDS ----
     const int x0 = x - 21, y0 = y - 21;
     const int row_bytes = (l == 0) ? L.w : L.stride;   // bytes of a row that may be touched
     const bool fast = (x0 >= 0) && (y0 >= 0) && (y + 21 < L.h) && (x + 21 < L.w) &&   // no reflection needed
                       (x + 27 < row_bytes);                                            // dword over-read stays in the row
+#ifndef DESC_NO_TILE3
+    if (fast && (l != 0 || l0_aligned)) {
+        // Rows start on a dword.  16 rows per pass, FOUR lanes per row: lane j of a row fetches dwords 3j .. 3j + 2 of the row segment
+        // in one 12-byte load; the dword that follows them comes from the next lane of the quad (one DPP move), and the lane
+        // funnel-shifts its three output dwords.  A quad of lanes is what the L1 serves per clock (it takes any 64-lane load as 16
+        // four-lane accesses): the 43 rows are 43 accesses in 3 loads instead of 135 in 9 (8-byte loads, 12 lanes per row), and
+        // the L1 was this kernel's busiest unit (profiles/r03_mem_counters.txt).
+        const int rr = lane >> 2, j = lane & 3;
+        const uint32_t voff = (uint32_t)(__mul24(y0 + rr, L.stride) + (x0 & ~3) + 12 * j);
+        const uint32_t xo = (uint32_t)x0 & 3u;
+        const int step16 = 16 * L.stride;
+        typedef uint32_t u32x3 __attribute__((ext_vector_type(3)));
+        typedef u32x3 __attribute__((aligned(4))) U3a4;
+        u32x3 gv[3];
+#pragma unroll
+        for (int p = 0; p < 3; p++) {
+            gv[p] = (u32x3){0u, 0u, 0u};
+            if (p < 2 || rr < DESC_RAW - 32) gv[p] = *(const __attribute__((address_space(1))) U3a4 *)(scalar_ptr(img + (long long)(p * step16)) + voff);
+        }
+#pragma unroll
+        for (int p = 0; p < 3; p++) {
+            const uint32_t nx = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)gv[p].x, 0xF9, 0xf, 0xf, false);   // quad_perm:[1,2,3,3]
+            if (p < 2 || rr < DESC_RAW - 32) {
+                uint32_t *dst = reinterpret_cast<uint32_t *>(&S.buf[(16 * p + rr) * DW_RAW_STRIDE + 12 * j]);
+                dst[0] = __builtin_amdgcn_alignbyte(gv[p].y, gv[p].x, xo);
+                dst[1] = __builtin_amdgcn_alignbyte(gv[p].z, gv[p].y, xo);
+                if (j < 3) dst[2] = __builtin_amdgcn_alignbyte(nx, gv[p].z, xo);   // the row's 12th dword lies past the 44-byte LDS row
+            }
+        }
+    } else
+#endif
     if (fast) {
         // 5 rows per pass, 12 lanes per row; lane d < 11 of a row fetches dwords d and d + 1 of the row segment in one
         // 8-byte load and funnel-shifts its own output dword out of them (no cross-lane traffic).
@@ -548,8 +599,8 @@ void orbx_launch_describe(const OrbxPlan &plan, const OrbxWork &wk, int nframes,
 {
     const OrbxLevel &L0 = plan.lv[0];
     const int l0_aligned = (((uintptr_t)L0.base | (uintptr_t)L0.stride | (uintptr_t)L0.frame_stride) & 3) == 0;
-    const int wg_per_frame = (plan.out_cap + 3) / 4;
+    const int wg_per_frame = (plan.out_cap + DESC_WAVES - 1) / DESC_WAVES;
     const int nwg = wg_per_frame * nframes;
-    hipLaunchKernelGGL(k_describe, dim3((nwg + 7) & ~7), dim3(256), 0, s, plan, wk, d_kps, d_desc, d_counts, d_status, l0_aligned,
+    hipLaunchKernelGGL(k_describe, dim3((nwg + 7) & ~7), dim3(64 * DESC_WAVES), 0, s, plan, wk, d_kps, d_desc, d_counts, d_status, l0_aligned,
                        wg_per_frame, nwg, wg_per_frame > 1 ? (uint32_t)((1ull << 32) / (unsigned)wg_per_frame + 1) : 0u);
 }

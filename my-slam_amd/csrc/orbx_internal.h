@@ -10,7 +10,9 @@
 #define ORBX_HALF_PATCH 15    // src/ORBextractor.cc:75
 
 // FAST: one wave per cell, 4 waves per workgroup (cell zone <= 59x59: wCell = ceil(width/floor(width/30)) < 60)
+#ifndef FAST_THREADS
 #define FAST_THREADS 256
+#endif
 
 #define ORBX_CNT_STRIDE 32
 #define ORBX_CNT(wk, plan, f, l) ((wk).cand_count[((f) * (plan).nlevels + (l)) * ORBX_CNT_STRIDE])
