@@ -264,7 +264,7 @@ ORBX_TRACE_DEFINE(g_desc_trace, orbx_debug_desc_trace)
 
 // 8 waves per SIMD: 63 VGPRs (68 without the bound) and 14 KB of LDS per workgroup; this kernel hides its latencies with resident waves
 #ifndef DESC_WAVES
-#define DESC_WAVES 4   // waves (keypoints) per workgroup
+#define DESC_WAVES 1   // waves (keypoints) per workgroup
 #endif
 __global__ __launch_bounds__(64 * DESC_WAVES, 8) void k_describe(
     OrbxPlan plan, OrbxWork wk, orbx_keypoint *__restrict__ kps, uint8_t *__restrict__ desc,

@@ -11,7 +11,7 @@
 
 // FAST: one wave per cell, 4 waves per workgroup (cell zone <= 59x59: wCell = ceil(width/floor(width/30)) < 60)
 #ifndef FAST_THREADS
-#define FAST_THREADS 256
+#define FAST_THREADS 64
 #endif
 
 #define ORBX_CNT_STRIDE 32

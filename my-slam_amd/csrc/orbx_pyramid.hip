@@ -1,5 +1,8 @@
 // orbx_pyramid.hip -- ComputePyramid (src/ORBextractor.cc:1109-1137 of WChen09/My-SLAM) on gfx950.
 #include "orbx_internal.h"
+#ifndef RESIZE_THREADS
+#define RESIZE_THREADS 256   // threads per workgroup of the 4x4-block resize kernels (independent threads)
+#endif
 
 // -------------------------------------------------------------------------------------------------
 // Pyramid: cv::resize INTER_LINEAR, CV_8UC1 fixed point (11-bit coefficients).  The per-column and
@@ -61,7 +64,7 @@ __global__ __launch_bounds__(256) void k_resize_area2(
 // level-0 buffer, which has no slack behind it.
 // -------------------------------------------------------------------------------------------------
 template <bool CHECK>
-__global__ __launch_bounds__(256) void k_resize_linear_4x4(
+__global__ __launch_bounds__(RESIZE_THREADS) void k_resize_linear_4x4(
     const uint8_t *__restrict__ src, int sw, int sh, int sstride, long long sframe,
     uint8_t *__restrict__ dst, int dw, int dh, int dstride, long long dframe, ResizeTab tab,
     const uint8_t *src_end, int nbx, int nblk, uint32_t rcp_nbx)
@@ -70,7 +73,7 @@ __global__ __launch_bounds__(256) void k_resize_linear_4x4(
     // The 4x4 blocks of a frame are numbered row-major and dealt to threads linearly: a wave is 64 consecutive
     // blocks (a 256-px strip, wrapping at the row end), so no lane is lost to tile quantisation -- with 2-D tiles of
     // 128 x 32 px a 533 x 400 level launched 25 % more waves than it has work for, a 179 x 134 one 70 % more.
-    const int t = blockIdx.x * 256 + threadIdx.x;
+    const int t = blockIdx.x * RESIZE_THREADS + threadIdx.x;
     if (t >= nblk) return;
     int by = rcp_nbx ? (int)__umulhi((uint32_t)t, rcp_nbx) : t;   // t / nbx (multiply-high by floor(2^32 / nbx) + 1, one correction; 0: nbx == 1)
     by -= (by * nbx > t) ? 1 : 0;
@@ -259,12 +262,12 @@ __device__ __forceinline__ void resize_block6(const uint8_t *S, int pitch, int r
 }
 
 template <bool CHECK>
-__global__ __launch_bounds__(256) void k_resize_linear_4x4s(
+__global__ __launch_bounds__(RESIZE_THREADS) void k_resize_linear_4x4s(
     const uint8_t *__restrict__ src, int sw, int sh, int sstride, long long sframe,
     uint8_t *__restrict__ dst, int dw, int dh, int dstride, long long dframe, ResizeTab tab,
     const uint8_t *src_end, int nbx, int nblk, uint32_t rcp_nbx)
 {
-    const int t = blockIdx.x * 256 + threadIdx.x;     // blocks numbered row-major, dealt linearly (see k_resize_linear_4x4)
+    const int t = blockIdx.x * RESIZE_THREADS + threadIdx.x;     // blocks numbered row-major, dealt linearly (see k_resize_linear_4x4)
     if (t >= nblk) return;
     int by = rcp_nbx ? (int)__umulhi((uint32_t)t, rcp_nbx) : t;
     by -= (by * nbx > t) ? 1 : 0;
@@ -708,19 +711,19 @@ void orbx_launch_resize(const OrbxLevel &src, const OrbxLevel &dst, const Resize
     } else {
         const int nbx = (dst.w + 3) / 4, nblk = nbx * ((dst.h + 3) / 4);
         const uint32_t rcp = nbx > 1 ? (uint32_t)((1ull << 32) / (unsigned)nbx + 1) : 0u;
-        dim3 grid((nblk + 255) / 256, 1, nframes);
+        dim3 grid((nblk + RESIZE_THREADS - 1) / RESIZE_THREADS, 1, nframes);
         if (mode == RESIZE_FAST6) {
             if (src_end)
-                hipLaunchKernelGGL(k_resize_linear_4x4s<true>, grid, dim3(256), 0, s, src.base, src.w, src.h, src.stride,
+                hipLaunchKernelGGL(k_resize_linear_4x4s<true>, grid, dim3(RESIZE_THREADS), 0, s, src.base, src.w, src.h, src.stride,
                                    src.frame_stride, dst.base, dst.w, dst.h, dst.stride, dst.frame_stride, tab, src_end, nbx, nblk, rcp);
             else
-                hipLaunchKernelGGL(k_resize_linear_4x4s<false>, grid, dim3(256), 0, s, src.base, src.w, src.h, src.stride,
+                hipLaunchKernelGGL(k_resize_linear_4x4s<false>, grid, dim3(RESIZE_THREADS), 0, s, src.base, src.w, src.h, src.stride,
                                    src.frame_stride, dst.base, dst.w, dst.h, dst.stride, dst.frame_stride, tab, src_end, nbx, nblk, rcp);
         } else if (src_end)
-            hipLaunchKernelGGL(k_resize_linear_4x4<true>, grid, dim3(256), 0, s, src.base, src.w, src.h, src.stride,
+            hipLaunchKernelGGL(k_resize_linear_4x4<true>, grid, dim3(RESIZE_THREADS), 0, s, src.base, src.w, src.h, src.stride,
                                src.frame_stride, dst.base, dst.w, dst.h, dst.stride, dst.frame_stride, tab, src_end, nbx, nblk, rcp);
         else
-            hipLaunchKernelGGL(k_resize_linear_4x4<false>, grid, dim3(256), 0, s, src.base, src.w, src.h, src.stride,
+            hipLaunchKernelGGL(k_resize_linear_4x4<false>, grid, dim3(RESIZE_THREADS), 0, s, src.base, src.w, src.h, src.stride,
                                src.frame_stride, dst.base, dst.w, dst.h, dst.stride, dst.frame_stride, tab, src_end, nbx, nblk, rcp);
     }
 }
