@@ -252,9 +252,11 @@ __global__ __launch_bounds__(FAST_THREADS) void k_fast_cells(OrbxPlan plan, Orbx
         const int t_lo = pass == 0 ? plan.ini_th : plan.min_th;
         if (pass == 1 && plan.min_th >= plan.ini_th) { FT_FLUSH; return; }
         {   // zero the score map (1-px zero ring = "outside the cell counts as 0")
-            uint32_t *z = reinterpret_cast<uint32_t *>(S.smap);
-            const int nz = (ZS * (zh + 2) + 3) >> 2;
-            for (int i = lane; i < nz; i += 64) z[i] = 0;
+            // 16 bytes per lane and store (the map starts on a 16-byte boundary and its size is a multiple of 16): two passes for a 30-row cell
+            static_assert((TS * TH) % 16 == 0 && (ZS * ZS) % 16 == 0 && sizeof(FastLds<TS, TH, ZS>) % 16 == 0, "score map alignment");
+            uint4 *z = reinterpret_cast<uint4 *>(__builtin_assume_aligned(S.smap, 16));
+            const int nz = (ZS * (zh + 2) + 15) >> 4;
+            for (int i = lane; i < nz; i += 64) z[i] = make_uint4(0u, 0u, 0u, 0u);
         }
         WSYNC();
 
@@ -355,16 +357,70 @@ __global__ __launch_bounds__(FAST_THREADS) void k_fast_cells(OrbxPlan plan, Orbx
         // Items are the listed corners, or every zone pixel if the list overflowed. ----
         unsigned long long *nms_masks = reinterpret_cast<unsigned long long *>(S.queue);   // the queue is empty and idle from here on
         static_assert(sizeof(S.queue) >= ((ZS * ZS + 63) / 64) * 8 && (TS * TH + ZS * ZS) % 8 == 0, "mask alias");
+        OrbxCand *out = wk.cand + (long long)f * plan.cand_frame + L.cand_off;
+        if (!cl_over) {
+            // The usual case: <= FAST_CLIST listed corners, i.e. <= 4 rounds of 64.  A round's position and score stay in registers and its
+            // mask of maxima in a scalar pair, so that the output pass neither re-reads the list and the score map nor goes through LDS masks.
+            constexpr int NR = (FAST_CLIST + 63) / 64;
+            uint32_t cxy[NR], crs[NR];
+            unsigned long long mk[NR];
+            int total = 0;
+#pragma unroll
+            for (int it = 0; it < NR; it++) {
+                mk[it] = 0ull; cxy[it] = 0u; crs[it] = 0u;
+                if (it * 64 < ncl) {
+                    const int idx = it * 64 + lane;
+                    bool ismax = false;
+                    if (idx < ncl) {
+                        const int pos = S.clist[idx];
+                        const int y = pos >> 6, x = pos & 63;
+                        const uint8_t *q = &S.smap[__umul24((uint32_t)y + 1u, (uint32_t)ZS) + x + 1];
+                        const uint32_t s = q[0];
+                        const uint32_t n0 = q[-1], n1 = q[1], n2 = q[-ZS - 1], n3 = q[-ZS], n4 = q[-ZS + 1], n5 = q[ZS - 1], n6 = q[ZS], n7 = q[ZS + 1];
+                        const uint32_t nm = max(max(max(n0, n1), max(n2, n3)), max(max(n4, n5), max(n6, n7)));
+                        ismax = s > nm;      // s > nm >= 0 implies s > 0
+                        cxy[it] = (uint32_t)(iniX + 3 + x) | ((uint32_t)(iniY + 3 + y) << 16);
+                        crs[it] = s;
+                    }
+                    mk[it] = __builtin_amdgcn_ballot_w64(ismax);
+                    total += __popcll(mk[it]);
+                }
+            }
+            FT(3);
+            if (total == 0) continue;   // nothing at this threshold: fall back to the lower one
+            int gbase = 0;
+            if (lane == 0) gbase = (int)atomicAdd(&ORBX_CNT(wk, plan, f, l), (uint32_t)total);
+            gbase = __shfl(gbase, 0);
+            int written = 0;
+#pragma unroll
+            for (int it = 0; it < NR; it++) {
+                if (mk[it] == 0ull) continue;
+                if ((mk[it] >> lane) & 1ull) {
+                    const int o = orbx_prefix_cnt(mk[it], gbase + written);
+                    if (o < L.cand_cap) {
+                        OrbxCand cnd;
+                        cnd.xy = cxy[it];
+                        cnd.resp = crs[it];
+                        out[o] = cnd;
+                    } else {
+                        atomicOr(&wk.errflags[f], (uint32_t)ERRF_CAND_OVERFLOW);
+                    }
+                }
+                written += __popcll(mk[it]);
+            }
+            FT(4);
+            FT_FLUSH;
+            return;
+        }
+        // the corner list overflowed (> FAST_CLIST corners in one cell): every zone pixel is an item
         int total = 0;
-        const int nitem = cl_over ? npx : ncl;
+        const int nitem = npx;
         const int niter = (nitem + 63) >> 6;
         for (int it = 0; it < niter; it++) {
             const int idx = it * 64 + lane;
             bool ismax = false;
             if (idx < nitem) {
-                int y, x;
-                if (cl_over) { y = (int)(__umul24((uint32_t)idx, rcp) >> 20); x = idx - (int)__umul24((uint32_t)y, (uint32_t)zw); }
-                else { const int pos = S.clist[idx]; y = pos >> 6; x = pos & 63; }
+                const int y = (int)(__umul24((uint32_t)idx, rcp) >> 20), x = idx - (int)__umul24((uint32_t)y, (uint32_t)zw);
                 const uint8_t *q = &S.smap[__umul24((uint32_t)y + 1u, (uint32_t)ZS) + x + 1];
                 // all nine reads at once and one comparison against the neighbours' maximum (v_max3_u32): a chain of &&
                 // would turn into eight divergent branches
@@ -384,16 +440,13 @@ __global__ __launch_bounds__(FAST_THREADS) void k_fast_cells(OrbxPlan plan, Orbx
         if (lane == 0) gbase = (int)atomicAdd(&ORBX_CNT(wk, plan, f, l), (uint32_t)total);
         gbase = __shfl(gbase, 0);
         WSYNC();
-        OrbxCand *out = wk.cand + (long long)f * plan.cand_frame + L.cand_off;
         int written = 0;
         for (int it = 0; it < niter; it++) {
             const unsigned long long mm = nms_masks[it];
             if (mm == 0) continue;
             const int idx = it * 64 + lane;
             if ((mm >> lane) & 1ull) {
-                int y, x;
-                if (cl_over) { y = (int)(__umul24((uint32_t)idx, rcp) >> 20); x = idx - (int)__umul24((uint32_t)y, (uint32_t)zw); }
-                else { const int pos = S.clist[idx]; y = pos >> 6; x = pos & 63; }
+                const int y = (int)(__umul24((uint32_t)idx, rcp) >> 20), x = idx - (int)__umul24((uint32_t)y, (uint32_t)zw);
                 const int o = orbx_prefix_cnt(mm, gbase + written);
                 if (o < L.cand_cap) {
                     OrbxCand cnd;
