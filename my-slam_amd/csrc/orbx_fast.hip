@@ -211,7 +211,53 @@ __global__ __launch_bounds__(FAST_THREADS) void k_fast_cells(OrbxPlan plan, Orbx
                     if (r < th) *reinterpret_cast<uint32_t *>(&S.tile[r * TS + FAST_PADL + 4 * cdw]) = __builtin_amdgcn_alignbyte(hi[i], lo[i], shv[i]);
                 }
             }
+        } else if (NDW <= 13 && ((iniX - 1) & ~3) + (NDW == 13 ? 56 : 52) <= (l == 0 ? L.w : L.stride)) {
+            // Rows start on a dword and 52 (56) bytes from the tile's aligned start lie inside the image row: 16 rows per pass, FOUR lanes
+            // per row.  Lanes 0..2 of a row fetch source dwords 4j .. 4j + 3 in one 16-byte load, lane 3 the 16 bytes that end with the 13th (14th); the
+            // dword behind a lane's four comes from its quad neighbour (one DPP move) and the lane funnel-shifts its four output dwords.
+            // Three passes instead of nine, scalar row bases with a 32-bit lane offset (the nine 64-bit multiply-adds of the 12-lanes-
+            // per-row form below are gone), all loads issued before the first is used: 55 -> 30 vector instructions for the tile.
+            const uint32_t sh = (uint32_t)(iniX - 1) & 3u;
+            const int rr = lane >> 2, j = lane & 3;
+            typedef const __attribute__((address_space(1))) uint8_t *gp8;
+            // lane 3's 16 bytes END with the row's 13th (14th) source dword: the same load instruction for every lane, no byte past the 52 (56)
+            constexpr int L3OFF = NDW == 13 ? 40 : 36;
+            const uint32_t coff = (uint32_t)(j < 3 ? 16 * j : L3OFF);
+            constexpr int NP3 = (TH + 15) / 16;
+            typedef uint32_t u32x4v __attribute__((ext_vector_type(4)));
+            typedef u32x4v __attribute__((aligned(4))) U4a4;
+            // the tile's aligned first byte is wave-uniform: pinned to scalar registers (global_load saddr form, 32-bit lane offsets)
+            const uint64_t b = reinterpret_cast<uint64_t>(img + ((iniX - 1) & ~3));
+            // (the builtin returns int: without the unsigned temporaries the low word would be SIGN-extended into the high one)
+            const uint32_t blo = (uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)b), bhi = (uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(b >> 32));
+            const gp8 rb = (gp8)(((uint64_t)bhi << 32) | blo);
+            u32x4v gv[NP3];
+#pragma unroll
+            for (int p = 0; p < NP3; p++) {
+                // every lane loads (rows past the tile re-read its last row: no divergent loads, nothing to merge afterwards)
+                const uint32_t row = (uint32_t)min(16 * p + rr, th - 1);
+                gv[p] = *(const __attribute__((address_space(1))) U4a4 *)(rb + (__umul24(row, (uint32_t)L.stride) + coff));
+            }
+            uint32_t *dst = reinterpret_cast<uint32_t *>(&S.tile[rr * TS + FAST_PADL + 16 * j]);
+#pragma unroll
+            for (int p = 0; p < NP3; p++) {
+                // the first source dword a lane holds for its left neighbour: dword 12 of the row for lane 3
+                const uint32_t first = j < 3 ? gv[p].x : (NDW == 13 ? gv[p].z : gv[p].w);
+                const uint32_t nx = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)first, 0xF9, 0xf, 0xf, false);   // quad_perm:[1,2,3,3]
+                if (16 * p + rr < th) {
+                    uint32_t *d = dst + p * (16 * TS / 4);
+                    if (j < 3) {
+                        d[0] = __builtin_amdgcn_alignbyte(gv[p].y, gv[p].x, sh);
+                        d[1] = __builtin_amdgcn_alignbyte(gv[p].z, gv[p].y, sh);
+                        d[2] = __builtin_amdgcn_alignbyte(gv[p].w, gv[p].z, sh);
+                        d[3] = __builtin_amdgcn_alignbyte(nx, gv[p].w, sh);
+                    } else if (NDW == 13) {
+                        d[0] = __builtin_amdgcn_alignbyte(gv[p].w, gv[p].z, sh);
+                    }
+                }
+            }
         } else {
+            // (cells at the right edge of a caller-owned level 0, and the 66-px tiles of tiny levels)
             // every pass's load is issued before the first one is used: one memory round trip for the tile instead of one per pass
             // (a loop of load / wait / store spent 8.5 k of a wave's 27.8 k clocks here, -DORBX_TRACE)
             const uint32_t sh = (uint32_t)(iniX - 1) & 3u;
