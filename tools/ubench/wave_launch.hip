@@ -70,6 +70,15 @@ int main()
         emit("120 registers", 120, 0, 256, spin, run<120, 0>(sink, 256, nwaves, spin, reps));
         emit("72 registers + 22 KiB LDS", 72, 22528, 256, spin, run<72, 22528>(sink, 256, nwaves, spin, reps));
     }
+    // Round 3: the footprints of k_describe (64 registers, 3.5 KiB of LDS per wave) and k_fast_cells (48 registers, 5 KiB) with their
+    // wave lifetimes, as one-wave and as four-wave workgroups: launch time against waves x lifetime / 8192 wave slots = what a slot
+    // loses between the end of one wave and the start of the next.
+    for (int spin : {6000, 14000, 25000}) {
+        emit("describe footprint, 1-wave workgroups", 64, 3584, 64, spin, run<64, 3584>(sink, 64, nwaves, spin, reps));
+        emit("describe footprint, 4-wave workgroups", 64, 14336, 256, spin, run<64, 14336>(sink, 256, nwaves, spin, reps));
+        emit("FAST footprint, 1-wave workgroups", 48, 5120, 64, spin, run<48, 5120>(sink, 64, nwaves, spin, reps));
+        emit("FAST footprint, 4-wave workgroups", 48, 20480, 256, spin, run<48, 20480>(sink, 256, nwaves, spin, reps));
+    }
     printf("\n]}\n");
     return 0;
 }
