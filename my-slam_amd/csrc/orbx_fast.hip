@@ -346,11 +346,13 @@ __global__ __launch_bounds__(FAST_THREADS) void k_fast_cells(OrbxPlan plan, Orbx
                 // differences and the non-zero tests do not care) of a dword are two u16 pairs after ONE full-rate AND each
                 // (a byte permute is a half-rate instruction).
 #define EV(X) as_us2((X) & 0x00FF00FFu)
-#define OD(X) as_us2((X) & 0xFF00FF00u)
                 fE = reject4<false>(EV(cC), tt, EV(dD), EV(dU), EV(d4), EV(d12));
-                fO = reject4<true>(OD(cC), ttO, OD(dD), OD(dU), OD(d4), OD(d12));
+                // The odd pixels are compared with the EVEN byte left in place underneath them (no AND): every u16 is odd << 8 | noise.
+                // min / max pick by the high byte first, so the high byte of every intermediate is exact, and a saturating difference
+                // of such values is non-zero whenever the difference of the high bytes is positive: no corner is lost.  When the high
+                // bytes are EQUAL the noise can make the difference non-zero -- a pixel more for stage 2, whose score is exact.
+                fO = reject4<true>(as_us2(cC), ttO, as_us2(dD), as_us2(dU), as_us2(d4), as_us2(d12));
 #undef EV
-#undef OD
             }
             // append the survivors of the 4 pixels: four ballots, one queue update (entry order is free)
             // (each ballot is taken straight from a compare and combined on the scalar unit; a ballot of a combined
