@@ -137,33 +137,43 @@ __device__ __forceinline__ float fast_atan2_deg(float y, float x)
 // (Cody-Waite reduction by pi/2 with a 33-bit head, Taylor kernels to r^19 / r^20 on |r| <= pi/4).
 // Canonical semantics = correctly rounded cosf/sinf; tests/tools/verify_sincos.py checks this
 // routine against the x87 long-double libm over every fp32 input of the domain.
+// A double constant held in a SCALAR register pair (two s_mov_b32) and opaque to the optimiser.  Left to itself the compiler puts each of the
+// 21 reduction / polynomial constants into a VECTOR register pair right before its use (v_fmac_f64 wants the addend in its destination):
+// 36 v_mov_b32 per keypoint, a third of this routine's vector instructions, all 64 lanes moving the same words.  v_fma_f64 takes the scalar
+// pair as its one scalar operand.  The value is unchanged: results are bit-identical (tests/tools/verify_sincos.py).
+__device__ __forceinline__ double KC(double c)
+{
+    unsigned long long u = __builtin_bit_cast(unsigned long long, c);
+    asm volatile("" : "+s"(u));
+    return __builtin_bit_cast(double, u);
+}
 __device__ __forceinline__ void sincos_cr(float theta, float *cs, float *sn)
 {
     const double x = (double)theta;
-    const double kd = rint(x * 0.6366197723675814);
+    const double kd = rint(x * KC(0.6366197723675814));
     const int k = (int)kd;
-    double r = fma(-kd, 1.5707963267341256, x);          // exact: 33-bit head times k <= 4
-    r = fma(-kd, 6.077100506506192e-11, r);
+    double r = fma(-kd, KC(1.5707963267341256), x);          // exact: 33-bit head times k <= 4
+    r = fma(-kd, KC(6.077100506506192e-11), r);
     const double z = r * r;
-    double ps = -8.22063524662433e-18;
-    ps = fma(ps, z, 2.8114572543455206e-15);
-    ps = fma(ps, z, -7.647163731819816e-13);
-    ps = fma(ps, z, 1.6059043836821613e-10);
-    ps = fma(ps, z, -2.505210838544172e-08);
-    ps = fma(ps, z, 2.7557319223985893e-06);
-    ps = fma(ps, z, -0.0001984126984126984);
-    ps = fma(ps, z, 0.008333333333333333);
-    ps = fma(ps, z, -0.16666666666666666);
+    double ps = KC(-8.22063524662433e-18);
+    ps = fma(ps, z, KC(2.8114572543455206e-15));
+    ps = fma(ps, z, KC(-7.647163731819816e-13));
+    ps = fma(ps, z, KC(1.6059043836821613e-10));
+    ps = fma(ps, z, KC(-2.505210838544172e-08));
+    ps = fma(ps, z, KC(2.7557319223985893e-06));
+    ps = fma(ps, z, KC(-0.0001984126984126984));
+    ps = fma(ps, z, KC(0.008333333333333333));
+    ps = fma(ps, z, KC(-0.16666666666666666));
     const double s = fma(r * z, ps, r);
-    double pc = 4.110317623312165e-19;
-    pc = fma(pc, z, -1.5619206968586225e-16);
-    pc = fma(pc, z, 4.779477332387385e-14);
-    pc = fma(pc, z, -1.1470745597729725e-11);
-    pc = fma(pc, z, 2.08767569878681e-09);
-    pc = fma(pc, z, -2.755731922398589e-07);
-    pc = fma(pc, z, 2.48015873015873e-05);
-    pc = fma(pc, z, -0.001388888888888889);
-    pc = fma(pc, z, 0.041666666666666664);
+    double pc = KC(4.110317623312165e-19);
+    pc = fma(pc, z, KC(-1.5619206968586225e-16));
+    pc = fma(pc, z, KC(4.779477332387385e-14));
+    pc = fma(pc, z, KC(-1.1470745597729725e-11));
+    pc = fma(pc, z, KC(2.08767569878681e-09));
+    pc = fma(pc, z, KC(-2.755731922398589e-07));
+    pc = fma(pc, z, KC(2.48015873015873e-05));
+    pc = fma(pc, z, KC(-0.001388888888888889));
+    pc = fma(pc, z, KC(0.041666666666666664));
     const double c = fma(z * z, pc, fma(z, -0.5, 1.0));
     double cv, sv;
     switch (k & 3) {
