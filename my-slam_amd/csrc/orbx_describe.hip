@@ -411,11 +411,25 @@ __global__ __launch_bounds__(64 * DESC_WAVES, 8) void k_describe(
                     if (p < 8 || rr < 3) dst[p * (5 * DW_RAW_STRIDE / 4)] = __builtin_amdgcn_alignbyte(gv[p].y, gv[p].x, xo[p]);
             }
         }
-    } else {   // tile crosses the image border (reflect-101): byte path
-        for (int i = lane; i < DESC_RAW * DESC_RAW; i += 64) {
-            const int r = i / DESC_RAW, c = i - r * DESC_RAW;
-            const int gy = reflect101(y0 + r, L.h), gx = reflect101(x0 + c, L.w);
-            S.buf[r * DW_RAW_STRIDE + c] = img[(long long)gy * L.stride + gx];
+    } else {   // tile crosses the image border (reflect-101): byte path, 2-7 % of a level's keypoints (those within 21 px of its edge)
+        // lane = tile column, its reflected source column computed once; one tile row per load with the reflected row index and the row's
+        // base address on the SCALAR unit (global_load_ubyte, scalar base + lane offset): about ten vector instructions for the tile.
+        // (The byte-per-lane loop over all 1849 pixels this replaces spent ~1000 on index arithmetic -- twice a whole keypoint.)
+        if (lane < DESC_RAW) {
+            const uint32_t gx = (uint32_t)reflect101(x0 + lane, L.w);
+            uint8_t *dst = &S.buf[lane];
+#pragma unroll 1
+            for (int r0 = 0; r0 < DESC_RAW; r0 += 11) {   // 43 = 3 x 11 + 10: eleven loads in flight
+                uint8_t v[11];
+#pragma unroll
+                for (int k = 0; k < 11; k++) {
+                    const int gy = reflect101(min(y0 + r0 + k, y0 + DESC_RAW - 1), L.h);   // wave-uniform
+                    v[k] = *(scalar_ptr(img + (long long)gy * L.stride) + gx);
+                }
+#pragma unroll
+                for (int k = 0; k < 11; k++)
+                    if (r0 + k < DESC_RAW) dst[(r0 + k) * DW_RAW_STRIDE] = v[k];
+            }
         }
     }
     DSYNC();
