@@ -24,7 +24,9 @@
     } while (0)
 
 #define FAST_PADL 4      // left pad (bytes) of every tile row so that dword g-1 exists for every group
+#ifndef FAST_CLIST
 #define FAST_CLIST 224   // corners listed per cell before NMS falls back to scanning the whole score map
+#endif
 
 template <int TS, int TH, int ZS>   // tile row stride (bytes, multiple of 4), tile rows, score-map stride/rows
 struct FastLds {
@@ -406,61 +408,107 @@ __global__ __launch_bounds__(FAST_THREADS) void k_fast_cells(OrbxPlan plan, Orbx
         unsigned long long *nms_masks = reinterpret_cast<unsigned long long *>(S.queue);   // the queue is empty and idle from here on
         static_assert(sizeof(S.queue) >= ((ZS * ZS + 63) / 64) * 8 && (TS * TH + ZS * ZS) % 8 == 0, "mask alias");
         OrbxCand *out = wk.cand + (long long)f * plan.cand_frame + L.cand_off;
-        if (!cl_over) {
-            // The usual case: <= FAST_CLIST listed corners, i.e. <= 4 rounds of 64.  A round's position and score stay in registers and its
-            // mask of maxima in a scalar pair, so that the output pass neither re-reads the list and the score map nor goes through LDS masks.
-            constexpr int NR = (FAST_CLIST + 63) / 64;
-            uint32_t cxy[NR], crs[NR];
-            unsigned long long mk[NR];
-            int total = 0;
+        // The corner list.  Usually the <= FAST_CLIST corners listed during stage 2.  When that list overflowed (a corner-dense cell: common
+        // on the small pyramid levels), the corners are listed again from the score map -- every non-zero byte is one -- into the drained
+        // queue and the old list together (FAST_BIG entries, contiguous), four pixels per lane and step like stage 1; that costs about a
+        // third of the per-pixel NMS over the whole zone it replaces (which remains for cells with more than FAST_BIG corners).
+        constexpr int FAST_BIG = 384 + FAST_CLIST - 1;   // the last entry is the trash slot of the compaction
+        typedef FastLds<TS, TH, ZS> LdsT;
+        static_assert(offsetof(LdsT, clist) == offsetof(LdsT, queue) + 384 * sizeof(uint16_t), "queue and list are contiguous");
+        const uint16_t *list = S.clist;
+        int nlist = ncl;
+        bool scan_all = false;
+        if (cl_over) {
+            uint16_t *big = S.queue;
+            constexpr int ND = ZS / 4;                              // dwords per score-map row
+            static_assert(ZS % 4 == 0, "score-map rows are whole dwords");
+            const uint32_t *sm32 = reinterpret_cast<const uint32_t *>(S.smap);
+            const int nt2 = zh * ND;
+            int cnt = 0;
+            for (int base = 0; base < nt2; base += 64) {
+                const int t = base + lane;
+                const int row = t / ND, jd = t - row * ND;          // division by a constant
+                const uint32_t w = t < nt2 ? sm32[(row + 1) * ND + jd] : 0u;   // bytes 4 jd .. 4 jd + 3 of map row row + 1: zone columns 4 jd - 1 ..
+                const unsigned long long b0 = __builtin_amdgcn_ballot_w64((w & 0x000000FFu) != 0u), b1 = __builtin_amdgcn_ballot_w64((w & 0x0000FF00u) != 0u);
+                const unsigned long long b2 = __builtin_amdgcn_ballot_w64((w & 0x00FF0000u) != 0u), b3 = __builtin_amdgcn_ballot_w64((w & 0xFF000000u) != 0u);
+                const int n = __popcll(b0) + __popcll(b1) + __popcll(b2) + __popcll(b3);
+                if (cnt + n > FAST_BIG) { scan_all = true; break; }   // wave-uniform
+                const bool k0 = __builtin_amdgcn_inverse_ballot_w64(b0), k1 = __builtin_amdgcn_inverse_ballot_w64(b1);
+                const bool k2 = __builtin_amdgcn_inverse_ballot_w64(b2), k3 = __builtin_amdgcn_inverse_ballot_w64(b3);
+                const int e0 = orbx_prefix_cnt(b3, orbx_prefix_cnt(b2, orbx_prefix_cnt(b1, orbx_prefix_cnt(b0, cnt))));
+                const int e1 = e0 + (k0 ? 1 : 0), e2 = e1 + (k1 ? 1 : 0), e3 = e2 + (k2 ? 1 : 0);
+                const int pz = (row << 6) + 4 * jd - 1;             // (y << 6) | x of byte 0 (x = -1 only for the zero ring's byte, never listed)
+                big[k0 ? e0 : FAST_BIG] = (uint16_t)pz;
+                big[k1 ? e1 : FAST_BIG] = (uint16_t)(pz + 1);
+                big[k2 ? e2 : FAST_BIG] = (uint16_t)(pz + 2);
+                big[k3 ? e3 : FAST_BIG] = (uint16_t)(pz + 3);
+                cnt += n;
+            }
+            WSYNC();
+            list = big;
+            nlist = cnt;
+        }
+        if (!scan_all) {
+            // <= 4 rounds of 64 corners at a time.  A round's position and score stay in registers and its mask of maxima in a scalar pair, so
+            // that the output pass neither re-reads the list and the score map nor goes through LDS masks; one atomic per chunk of 256
+            // reserves the output range (the order of a level's candidates is free: the quadtree sorts).
+            constexpr int NR = 4;
+            int total_all = 0;
+            for (int c0 = 0; c0 < nlist; c0 += 64 * NR) {
+                uint32_t cxy[NR], crs[NR];
+                unsigned long long mk[NR];
+                int total = 0;
 #pragma unroll
-            for (int it = 0; it < NR; it++) {
-                mk[it] = 0ull; cxy[it] = 0u; crs[it] = 0u;
-                if (it * 64 < ncl) {
-                    const int idx = it * 64 + lane;
-                    bool ismax = false;
-                    if (idx < ncl) {
-                        const int pos = S.clist[idx];
-                        const int y = pos >> 6, x = pos & 63;
-                        const uint8_t *q = &S.smap[__umul24((uint32_t)y + 1u, (uint32_t)ZS) + x + 1];
-                        const uint32_t s = q[0];
-                        const uint32_t n0 = q[-1], n1 = q[1], n2 = q[-ZS - 1], n3 = q[-ZS], n4 = q[-ZS + 1], n5 = q[ZS - 1], n6 = q[ZS], n7 = q[ZS + 1];
-                        const uint32_t nm = max(max(max(n0, n1), max(n2, n3)), max(max(n4, n5), max(n6, n7)));
-                        ismax = s > nm;      // s > nm >= 0 implies s > 0
-                        cxy[it] = (uint32_t)(iniX + 3 + x) | ((uint32_t)(iniY + 3 + y) << 16);
-                        crs[it] = s;
+                for (int it = 0; it < NR; it++) {
+                    mk[it] = 0ull; cxy[it] = 0u; crs[it] = 0u;
+                    if (c0 + it * 64 < nlist) {
+                        const int idx = c0 + it * 64 + lane;
+                        bool ismax = false;
+                        if (idx < nlist) {
+                            const int pos = list[idx];
+                            const int y = pos >> 6, x = pos & 63;
+                            const uint8_t *q = &S.smap[__umul24((uint32_t)y + 1u, (uint32_t)ZS) + x + 1];
+                            const uint32_t s = q[0];
+                            const uint32_t n0 = q[-1], n1 = q[1], n2 = q[-ZS - 1], n3 = q[-ZS], n4 = q[-ZS + 1], n5 = q[ZS - 1], n6 = q[ZS], n7 = q[ZS + 1];
+                            const uint32_t nm = max(max(max(n0, n1), max(n2, n3)), max(max(n4, n5), max(n6, n7)));
+                            ismax = s > nm;      // s > nm >= 0 implies s > 0
+                            cxy[it] = (uint32_t)(iniX + 3 + x) | ((uint32_t)(iniY + 3 + y) << 16);
+                            crs[it] = s;
+                        }
+                        mk[it] = __builtin_amdgcn_ballot_w64(ismax);
+                        total += __popcll(mk[it]);
                     }
-                    mk[it] = __builtin_amdgcn_ballot_w64(ismax);
-                    total += __popcll(mk[it]);
+                }
+                if (total == 0) continue;
+                total_all += total;
+                int gbase = 0;
+                if (lane == 0) gbase = (int)atomicAdd(&ORBX_CNT(wk, plan, f, l), (uint32_t)total);
+                gbase = __shfl(gbase, 0);
+                int written = 0;
+#pragma unroll
+                for (int it = 0; it < NR; it++) {
+                    if (mk[it] == 0ull) continue;
+                    if ((mk[it] >> lane) & 1ull) {
+                        const int o = orbx_prefix_cnt(mk[it], gbase + written);
+                        if (o < L.cand_cap) {
+                            OrbxCand cnd;
+                            cnd.xy = cxy[it];
+                            cnd.resp = crs[it];
+                            out[o] = cnd;
+                        } else {
+                            atomicOr(&wk.errflags[f], (uint32_t)ERRF_CAND_OVERFLOW);
+                        }
+                    }
+                    written += __popcll(mk[it]);
                 }
             }
             FT(3);
-            if (total == 0) continue;   // nothing at this threshold: fall back to the lower one
-            int gbase = 0;
-            if (lane == 0) gbase = (int)atomicAdd(&ORBX_CNT(wk, plan, f, l), (uint32_t)total);
-            gbase = __shfl(gbase, 0);
-            int written = 0;
-#pragma unroll
-            for (int it = 0; it < NR; it++) {
-                if (mk[it] == 0ull) continue;
-                if ((mk[it] >> lane) & 1ull) {
-                    const int o = orbx_prefix_cnt(mk[it], gbase + written);
-                    if (o < L.cand_cap) {
-                        OrbxCand cnd;
-                        cnd.xy = cxy[it];
-                        cnd.resp = crs[it];
-                        out[o] = cnd;
-                    } else {
-                        atomicOr(&wk.errflags[f], (uint32_t)ERRF_CAND_OVERFLOW);
-                    }
-                }
-                written += __popcll(mk[it]);
-            }
+            if (total_all == 0) continue;   // nothing at this threshold: fall back to the lower one
             FT(4);
             FT_FLUSH;
             return;
         }
-        // the corner list overflowed (> FAST_CLIST corners in one cell): every zone pixel is an item
+        // more corners than the big list holds (noise-like cells): every zone pixel is an item
         int total = 0;
         const int nitem = npx;
         const int niter = (nitem + 63) >> 6;
