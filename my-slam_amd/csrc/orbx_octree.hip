@@ -766,7 +766,9 @@ __global__ __launch_bounds__(T) void k_octree(OrbxPlan plan, OrbxWork wk)
     extern __shared__ __attribute__((aligned(16))) unsigned char oct_lds[];
     __shared__ OctShared<T> sh;
     const int tid = threadIdx.x;
-    const int l = blockIdx.x, f = blockIdx.y;
+    // Level-major order (x = frame, y = level): the level-0 workgroups -- the longest chains -- are dispatched first, and a workgroup's XCD is
+    // frame mod 8 instead of its LEVEL (with x = level all level-0 chains shared the 32 CUs of XCD 0, two to a CU).
+    const int l = blockIdx.y, f = blockIdx.x;
     const OrbxLevel &L = plan.lv[l];
     const int cap = L.list_cap;
     const int N = L.quota;
@@ -833,7 +835,7 @@ size_t orbx_octree_lds_bytes(int list_cap_max, int ft_entries, int map_entries) 
 
 void orbx_launch_octree(const OrbxPlan &plan, const OrbxWork &wk, int nframes, size_t lds_bytes, hipStream_t s)
 {
-    dim3 grid(plan.nlevels, nframes);
+    dim3 grid(nframes, plan.nlevels);
     if (plan.oct_big) {   // 1080p-class levels: tens of thousands of keys per level
         if (lds_bytes > 32 * 1024)
             (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_octree<1024>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
