@@ -20,8 +20,8 @@ __constant__ uint4 c_mom_tab[256];
 // Blur task lists.  Only blurred pixels a rotated sample can land on are produced: |rotated p| <= |p|max and each
 // coordinate is rounded, so integer (r, q) with r*r + q*q <= (|p|max + 0.72)^2 (1125 of the 37 x 37 = 1369 positions;
 // |p|max = 18.38 for the ORB pattern).  Row task = (row pair, 4-column group) -> 189 of 220; column task = 2 x 2 output
-// block -> 300 of 361.  Entries: row: raw byte offset | P dword offset << 16; column: P dword offset | bl byte offset
-// << 10 | first column << 21 | (second row exists) << 27.  0xFFFFFFFF = no task.
+// block -> 300 of 361.  Entries: row: raw byte offset | P dword offset << 16; column: P BYTE offset | bl byte offset
+// << 16 (two halves the kernel uses as they are; a task's first column is its bl offset mod 80).  0xFFFFFFFF = no task.
 __constant__ uint32_t c_row_task[192];
 __constant__ uint32_t c_col_task[320];
 // The same eight words per lane as two 16-byte entries: [lane] = (row task 0..2, column task 0), [64 + lane] = (column task 1..4).
@@ -76,7 +76,7 @@ int orbx_upload_constants(const int umax[16], const int gauss_k[7])
                 bool ok = false;
                 for (int i = 2 * q; i <= 2 * q + 1 && i < 37; i++)
                     for (int j = 2 * cp; j <= 2 * cp + 1 && j < 37; j++) ok = ok || need[i][j];
-                if (ok) { if (nc >= 320) return -1; ct[nc++] = (uint32_t)(q * 40 + 2 * cp) | ((uint32_t)(80 * q + 2 * cp) << 10) | ((uint32_t)(2 * cp) << 21) | ((2 * q + 1 < 37 ? 1u : 0u) << 27); }
+                if (ok) { if (nc >= 320) return -1; ct[nc++] = (uint32_t)(4 * (q * 40 + 2 * cp)) | ((uint32_t)(80 * q + 2 * cp) << 16); }   // P byte offset | bl byte offset << 16
             }
         for (; nr < 192; nr++) rt[nr] = 0xFFFFFFFFu;
         for (; nc < 320; nc++) ct[nc] = 0xFFFFFFFFu;
@@ -517,9 +517,8 @@ __global__ __launch_bounds__(64 * DESC_WAVES, 8) void k_describe(
         for (int it = 0; it < 5; it++) {
             const uint32_t te = ctask[it];
             if (te != 0xFFFFFFFFu) {
-                const int c = (int)((te >> 21) & 63u);
-                const uint32_t *pin = &reinterpret_cast<const uint32_t *>(S.buf)[te & 1023u];
-                uint8_t *pout = &bl[(te >> 10) & 2047u];
+                const uint32_t *pin = reinterpret_cast<const uint32_t *>(&S.buf[te & 0xFFFFu]);
+                uint8_t *pout = &bl[te >> 16];
                 typedef unsigned short us2 __attribute__((ext_vector_type(2)));
                 // volatile: four ds_read_b64 (two lane groups of 32, banks mod 64: 2 LDS cycles each when conflict-free).  Left alone the
                 // compiler pairs them into ds_read2_b64, which is serviced as 2 x 4 groups of 16 lanes on 32 banks: 148 instead of 76
@@ -549,6 +548,7 @@ __global__ __launch_bounds__(64 * DESC_WAVES, 8) void k_describe(
                 // pixels reaches 257: the taps add up to 257) and the packing into two bytes are one v_sat_pk_u8_i16
                 uint32_t pe = __builtin_amdgcn_perm(e1, e0, 0x07060302u), po = __builtin_amdgcn_perm(o1, o0, 0x07060302u);
                 if (simd_cols != 0) {   // wave-uniform; x86 SSE2 path for columns < simd_cols: an exact .5 tie rounds to even
+                    const int c = (int)((te >> 16) % 80u);   // first column of the task: bl offset = 80 q + column
                     const uint32_t s4[4] = {e0, e1, o0, o1};
                     uint32_t dec[4];
 #pragma unroll
